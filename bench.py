@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: G body-body interactions/s of the naive O(N^2) step at N = 2^20
+(BASELINE.json metric), on 1..8 MI355X of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n BODIES] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path: pair-force accumulation of every owned target against all N sources
+(self pairs counted, as the reference evaluates them, benchmark.cpp:434) + forward-Euler update + (N>1) the
+all-gather of posX/posY.  Inputs are resident in HBM before the timed region.  Total work is fixed as N grows
+(strong scaling): the 2^20 bodies are sharded over the ranks.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+FLOP_PER_INTERACTION = 20     # BASELINE.json convention
+
+
+def cpu_baseline(budget_s=12.0):
+    """The reference's own OpenMP+AVX2 naive loop (oracle/_ref, built from /root/reference/benchmark.cpp by
+    oracle/build_ref.sh) timed on this host: N=65536, as many steps as fit the budget (>= 3)."""
+    O = entry.load_oracle()
+    import ctypes
+    try:
+        cores = ctypes.CDLL("libgomp.so.1").omp_get_max_threads()
+    except OSError:
+        cores = os.cpu_count()
+    n = 65536
+    if O.ref_available():
+        b = O.init_disc(n, seed=12345)
+        O.ref_run(n, use_barnes_hut=0, nsteps=1, bodies=b)            # warm-up (page faults, thread pool)
+        ms = []
+        t0 = time.time()
+        while len(ms) < 3 or (time.time() - t0 < budget_s and len(ms) < 200):
+            r = O.ref_run(n, use_barnes_hut=0, nsteps=2, bodies=b)
+            ms.extend(r["step_ms"].tolist())
+        med = float(np.median(ms))
+        return dict(value=n * n / (med * 1e-3) / 1e9, unit="G interactions/s", cores=int(cores), kind="reference",
+                    sample=f"reference benchmark.cpp naive loop (OpenMP+AVX2, -O3 -ffast-math, x86-64-v3), N={n}, "
+                           f"median of {len(ms)} steps, {med:.1f} ms/step; rate is N-independent (compute-bound, "
+                           f"SURVEY.md §6.2) so N=2^20 would take ~{med * 256 / 1e3:.0f} s/step")
+    # no compiled reference on this box: time the plain-C restatement instead
+    b = O.init_disc(16384, seed=12345)
+    t0 = time.time()
+    O.naive_accel_f32(b)
+    dt = time.time() - t0
+    return dict(value=16384 ** 2 / dt / 1e9, unit="G interactions/s", cores=int(cores), kind="port",
+                sample="oracle/nbody_oracle.c f32 restatement, N=16384, one force pass")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=1 << 20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = entry.load_package()
+    from nbody_amd.sharded import ShardedNaiveSim, owned_targets
+    O = entry.load_oracle()          # only for the synthetic inputs (seeded disc) and the cpu_baseline leg
+    n = args.n
+    bodies = O.init_disc(n, seed=12345)      # benchmark.cpp:317-339, seed fixed
+
+    sim = ShardedNaiveSim(pkg, n, rank, world, device=local_rank, dt=0.05, dist=dist)
+    sim.upload(*bodies.arrays())
+    my_targets = owned_targets(n, sim.spans, rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sim.step(args.warmup)
+    barrier()
+    sim.sim.profile(True).profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    sim.step(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    force_ms, force_launches = sim.sim.profile_read(0)
+    integ_ms, integ_launches = sim.sim.profile_read(1)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = n * float(n) * args.steps / elapsed / 1e9          # whole job: all N^2 pairs of every step
+        k_ms = force_ms / max(1, force_launches)
+        achieved = FLOP_PER_INTERACTION * float(my_targets) * n / (k_ms * 1e-3) / 1e12
+        info = sim.sim.info()
+        line = {
+            "metric": "G body-body interactions/s, N=1M naive step",
+            "value": value, "unit": "G interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"naive O(N^2) step, N={n}, seeded uniform-(angle,r) disc (benchmark.cpp:317-339, "
+                                   f"seed 12345), spread=400 mass=1000 radius=8 dt=0.05",
+                       "num_bodies": n, "parallelism": f"i-shard x{world}, all-gather posX/posY per step",
+                       "force_variant": info["force_variant"], "j_slices": info["j_slices"]},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "kernel": "force_naive_kernel", "kernel_ms": k_ms, "launches": int(force_launches),
+                         "note": "FP32 vector (no MFMA: elementwise-transcendental pair loop); algorithmic flop = "
+                                 "20 x owned targets x N sources per launch (rank 0); integrate_kernel "
+                                 f"{integ_ms / max(1, integ_launches) * 1e3:.1f} us/launch"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    sim.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

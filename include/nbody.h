@@ -1,0 +1,130 @@
+/* nbody.h — C-ABI of the MI355X-native physics step for fejzo9/N-Body.
+ *
+ * The reference has no operator / plugin / FFI interface: its physics is inline in main()
+ * between `physicsStart` and `physicsEnd` (benchmark.cpp:352-513, main.cpp:483-644) and works
+ * in place on the BodyDataSoA vectors (benchmark.cpp:24-49), parameterised by the locals
+ * useBarnesHut/useParallel/n/spread/mass/theta/dt (benchmark.cpp:300-306; the config.json keys of
+ * main.cpp:374-390).  This header therefore DEFINES the drop-in seam: a host program replaces
+ * that block by nbody_upload (once) + nbody_step (per frame) + nbody_download (when it needs the
+ * positions, e.g. main.cpp:650-653).  INTEGRATION.md shows the edit.
+ *
+ * Conventions: plain C, no C++/torch types; every float array is caller-owned host memory of
+ * length num_bodies unless the name says "device"; no alignment requirement (the reference uses
+ * unaligned loads throughout, benchmark.cpp:375-401); one context is driven from one host thread;
+ * errors are negative return codes + nbody_last_error(); nothing throws.  There is NO CPU
+ * fallback: without a gfx950 device nbody_create fails with NBODY_ERR_NO_DEVICE.
+ */
+#ifndef NBODY_H_
+#define NBODY_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBODY_ABI_VERSION 1
+
+enum {
+    NBODY_OK = 0,
+    NBODY_ERR_INVALID = -1,    /* bad argument / bad state            */
+    NBODY_ERR_NO_DEVICE = -2,  /* no usable HIP device                */
+    NBODY_ERR_HIP = -3,        /* a HIP runtime call failed           */
+    NBODY_ERR_UNSUPPORTED = -4 /* feature not built for this config   */
+};
+
+typedef struct nbody_ctx nbody_ctx; /* opaque; owns all device memory */
+
+/* Replaces the parameter block benchmark.cpp:300-306 / main.cpp:337-343 (+ config.json keys). */
+typedef struct nbody_config {
+    int32_t num_bodies;      /* numBodies                                                        */
+    float   spread;          /* spread: Barnes-Hut root box is [-spread,spread]^2 (benchmark.cpp:169) */
+    float   mass;            /* mass: informational (per-body masses come from nbody_upload)      */
+    float   dt;              /* dt                                                               */
+    float   theta;           /* theta                                                            */
+    int32_t use_barnes_hut;  /* useBarnesHut: 0 = naive O(N^2) (benchmark.cpp:405), 1 = BH (:354)  */
+    int32_t use_parallel;    /* useParallel: in the BH branch 0 means "build tree, do nothing"
+                                (benchmark.cpp:359); ignored by the naive branch, as in the reference */
+    int32_t ref_compat;      /* 1: reproduce the reference's quirks — bodies with index >= N-N%8 are
+                                never targets nor integrated (benchmark.cpp:423,486,368) and the BH
+                                walk votes per group of 8 consecutive bodies (benchmark.cpp:264-266).
+                                0: every body is a target; BH walk still uses the group-of-8 vote.  */
+    int32_t device;          /* HIP device ordinal; -1 = current device                           */
+    /* i-body shard owned by this context (multi-GPU: one context per GPU/process).
+       All num_bodies bodies are sources; targets are [shard_begin, shard_begin+shard_count).
+       shard_count == 0 means the whole range.  Use nbody_shard_range() to compute it.            */
+    int32_t shard_begin;
+    int32_t shard_count;
+    int32_t force_variant;   /* 0 = auto (chosen at upload from the m/radius arrays),
+                                1 = uniform mass+radius, 2 = per-body mass+radius, 3 = exact-general */
+    int32_t reserved[4];
+} nbody_config;
+
+/* Defaults = benchmark.cpp:300-306 (BH on, n=10000, spread=400, mass=1000, theta=1, dt=0.05). */
+void nbody_default_config(nbody_config *cfg);
+
+/* Contiguous i-shard of rank `rank` of `nranks`; boundaries are multiples of 8 so the reference's
+   groups of 8 (benchmark.cpp:421) never straddle two GPUs.  Pure host arithmetic.                 */
+int nbody_shard_range(int32_t num_bodies, int32_t nranks, int32_t rank, int32_t *begin, int32_t *count);
+
+int nbody_create(const nbody_config *cfg, nbody_ctx **out);
+void nbody_destroy(nbody_ctx *ctx);
+
+/* Run all of the context's work on an existing HIP stream (hipStream_t passed as void*), e.g. the
+   stream a framework's collectives are ordered against.  NULL restores the context's own stream. */
+int nbody_set_stream(nbody_ctx *ctx, void *hip_stream);
+
+/* = BodyDataSoA::m/posX/posY/velX/velY/radius .data() (benchmark.cpp:28-33).  Synchronous. */
+int nbody_upload(nbody_ctx *ctx, const float *m, const float *posX, const float *posY,
+                 const float *velX, const float *velY, const float *radius);
+
+/* Enqueue nsteps iterations of the block benchmark.cpp:354-511 (force + forward Euler).  Returns
+   once enqueued.  In a sharded context only the owned i-range is advanced; the caller must call
+   nbody_exchange_* (or its own all-gather on nbody_device_ptr) between steps, so nsteps must be 1. */
+int nbody_step(nbody_ctx *ctx, int32_t nsteps);
+
+/* Only the force phase (accelerations of the current positions), no integration. */
+int nbody_compute_accel(nbody_ctx *ctx);
+
+int nbody_sync(nbody_ctx *ctx);
+
+/* Copies the state back (syncs).  Any pointer may be NULL.  main.cpp:650-653 needs posX/posY only. */
+int nbody_download(nbody_ctx *ctx, float *posX, float *posY, float *velX, float *velY);
+
+/* Parity hook: the accelerations evaluated by the last nbody_step / nbody_compute_accel, i.e. the
+   reference's tmp_accX/tmp_accY (benchmark.cpp:412-413, 476-477).  Entries outside the owned shard
+   (and, in ref_compat, the N%8 tail) are 0.  Syncs. */
+int nbody_get_accel(nbody_ctx *ctx, float *accX, float *accY);
+
+/* {Ekin, Epot, Px, Py, Lz} of the current state, f64 accumulation on the GPU.  The reference has
+   no counterpart; Epot uses the potential consistent with its clamped force.  Syncs. */
+int nbody_diagnostics(nbody_ctx *ctx, double out[5]);
+
+/* Device pointers of the SoA state for zero-copy interop (RCCL all-gather of the position arrays,
+   SURVEY.md §8e).  which: 0 m, 1 posX, 2 posY, 3 velX, 4 velY, 5 radius, 6 accX, 7 accY. */
+void *nbody_device_ptr(nbody_ctx *ctx, int32_t which);
+
+/* Per-kernel timing with hipEvents on the context's stream.  which: 0 = force (naive pair kernel or
+   BH walk), 1 = integrate, 2 = tree build (BH).  Accumulates while enabled. */
+int nbody_profile_enable(nbody_ctx *ctx, int32_t on);
+int nbody_profile_read(nbody_ctx *ctx, int32_t which, double *total_ms, int64_t *launches);
+int nbody_profile_reset(nbody_ctx *ctx);
+
+/* Introspection for tests/bench: which force variant upload selected (1..3), grid geometry. */
+int nbody_get_info(nbody_ctx *ctx, int32_t *force_variant, int32_t *j_slices, int32_t *blocks);
+
+/* Barnes-Hut tree read-back (parity hook for QuadTree::pool / lastPoolIndex, benchmark.cpp:73-74).
+   Returns the number of nodes of the last build; copies at most cap 48-byte QuadNode records
+   (layout benchmark.cpp:52-60) when out != NULL.  Node ORDER differs from the reference's insertion
+   order; compare as a set / via canonical traversal. */
+int64_t nbody_bh_tree_nodes(nbody_ctx *ctx, void *out, int64_t cap);
+/* {node visits, accepted nodes} summed over all groups of the last BH walk. */
+int nbody_bh_counters(nbody_ctx *ctx, int64_t out[2]);
+
+const char *nbody_last_error(void); /* thread-local, never NULL */
+int nbody_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_H_ */

@@ -1,0 +1,483 @@
+// nbody_capi.hip — the C-ABI of include/nbody.h on top of the gfx950 kernels.
+//
+// Host-side step driver: replaces the block between physicsStart and physicsEnd of the reference
+// (benchmark.cpp:352-513).  One context = one GPU = one i-shard; everything is enqueued on one HIP
+// stream, nothing in the step path allocates or synchronises.
+#include "../../include/nbody.h"
+#include "force_naive.hip.h"
+#include "diagnostics.hip.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace nbody;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(NBODY_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+struct EventPair { hipEvent_t a, b; };
+
+struct Profiler {
+    bool on = false;
+    std::vector<EventPair> pool[3];   // per kernel class
+    size_t used[3] = {0, 0, 0};
+    double total_ms[3] = {0, 0, 0};
+    int64_t launches[3] = {0, 0, 0};
+};
+
+constexpr int kMaxSlices = 64;
+constexpr size_t kMaxEventsPerClass = 4096;
+
+}  // namespace
+
+struct nbody_ctx {
+    nbody_config cfg{};
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // SoA state in HBM: one float[n] per field, 256-B aligned by hipMalloc.
+    float *m = nullptr, *px = nullptr, *py = nullptr, *vx = nullptr, *vy = nullptr, *radius = nullptr;
+    float* c = nullptr;              // per-body clamp constant, see force_naive.hip.h
+    float *ax = nullptr, *ay = nullptr;      // total accelerations [n]
+    float *pax = nullptr, *pay = nullptr;    // j-slice partials [slices][i_stride]
+    double* diag_partials = nullptr;
+    int diag_blocks = 0;
+    int i_begin = 0, i_end = 0;      // targets actually advanced (shard ∩ ref_compat limit)
+    int i_stride = 0;
+    int variant = 0, slices = 1, k_per_lane = 2, j_per_slice = 0, blocks_x = 0;
+    float uni_m = 0, uni_c = 0;
+    bool uploaded = false;
+    Profiler prof;
+};
+
+namespace {
+
+int profile_begin(nbody_ctx* ctx, int cls, EventPair** out)
+{
+    *out = nullptr;
+    Profiler& p = ctx->prof;
+    if (!p.on) return NBODY_OK;
+    if (p.used[cls] >= kMaxEventsPerClass) {   // drain before reusing the pool
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < p.used[cls]; ++i) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, p.pool[cls][i].a, p.pool[cls][i].b));
+            p.total_ms[cls] += ms;
+        }
+        p.used[cls] = 0;
+    }
+    if (p.used[cls] == p.pool[cls].size()) {
+        EventPair ep;
+        HIP_TRY(hipEventCreate(&ep.a));
+        HIP_TRY(hipEventCreate(&ep.b));
+        p.pool[cls].push_back(ep);
+    }
+    EventPair* ep = &p.pool[cls][p.used[cls]++];
+    HIP_TRY(hipEventRecord(ep->a, ctx->stream));
+    *out = ep;
+    return NBODY_OK;
+}
+
+int profile_end(nbody_ctx* ctx, int cls, EventPair* ep)
+{
+    if (!ep) return NBODY_OK;
+    HIP_TRY(hipEventRecord(ep->b, ctx->stream));
+    ctx->prof.launches[cls]++;
+    return NBODY_OK;
+}
+
+template <int V, int K>
+void launch_force(const ForceArgs& a, dim3 grid, hipStream_t s)
+{
+    force_naive_kernel<V, K><<<grid, dim3(kBlock), 0, s>>>(a);
+}
+
+int enqueue_force(nbody_ctx* ctx)
+{
+    if (ctx->i_end <= ctx->i_begin) return NBODY_OK;
+    ForceArgs a{};
+    a.px = ctx->px; a.py = ctx->py; a.m = ctx->m; a.c = ctx->c;
+    a.pax = ctx->pax; a.pay = ctx->pay;
+    a.n = ctx->cfg.num_bodies;
+    a.i_begin = ctx->i_begin; a.i_end = ctx->i_end; a.i_stride = ctx->i_stride;
+    a.j_per_slice = ctx->j_per_slice;
+    a.uni_c = ctx->uni_c; a.uni_m = ctx->uni_m;
+    dim3 grid(ctx->blocks_x, ctx->slices);
+    EventPair* ep;
+    int rc = profile_begin(ctx, 0, &ep);
+    if (rc) return rc;
+    const int K = ctx->k_per_lane;
+    switch (ctx->variant) {
+        case kUniform: (K == 1) ? launch_force<kUniform, 1>(a, grid, ctx->stream) : launch_force<kUniform, 2>(a, grid, ctx->stream); break;
+        case kPerBody: (K == 1) ? launch_force<kPerBody, 1>(a, grid, ctx->stream) : launch_force<kPerBody, 2>(a, grid, ctx->stream); break;
+        case kExact:   (K == 1) ? launch_force<kExact, 1>(a, grid, ctx->stream)   : launch_force<kExact, 2>(a, grid, ctx->stream); break;
+        default: return fail(NBODY_ERR_INVALID, "no force variant selected");
+    }
+    HIP_TRY(hipGetLastError());
+    return profile_end(ctx, 0, ep);
+}
+
+int enqueue_integrate(nbody_ctx* ctx, int advance)
+{
+    if (ctx->i_end <= ctx->i_begin) return NBODY_OK;
+    IntegrateArgs a{};
+    a.px = ctx->px; a.py = ctx->py; a.vx = ctx->vx; a.vy = ctx->vy;
+    a.pax = ctx->pax; a.pay = ctx->pay; a.ax = ctx->ax; a.ay = ctx->ay;
+    a.i_begin = ctx->i_begin; a.i_end = ctx->i_end; a.i_stride = ctx->i_stride; a.slices = ctx->slices;
+    a.dt = ctx->cfg.dt; a.advance = advance;
+    const int nt = ctx->i_end - ctx->i_begin;
+    EventPair* ep;
+    int rc = profile_begin(ctx, 1, &ep);
+    if (rc) return rc;
+    integrate_kernel<<<dim3((nt + 255) / 256), dim3(256), 0, ctx->stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    return profile_end(ctx, 1, ep);
+}
+
+// Geometry of the force launch: enough workgroups to fill 256 CUs several times over.
+void plan_force(nbody_ctx* ctx)
+{
+    const int n = ctx->cfg.num_bodies;
+    const int nt = ctx->i_end - ctx->i_begin;
+    ctx->k_per_lane = nt >= (1 << 17) ? 2 : 1;
+    ctx->blocks_x = (nt + kBlock * ctx->k_per_lane - 1) / (kBlock * ctx->k_per_lane);
+    if (ctx->blocks_x < 1) ctx->blocks_x = 1;
+    const int max_slices_by_n = (n + kTileJ - 1) / kTileJ;
+    int want = (4096 + ctx->blocks_x - 1) / ctx->blocks_x;   // aim for >= 4096 workgroups
+    if (want > kMaxSlices) want = kMaxSlices;
+    if (want > max_slices_by_n) want = max_slices_by_n;
+    if (want < 1) want = 1;
+    int jps = ((n + want - 1) / want + kTileJ - 1) / kTileJ * kTileJ;
+    ctx->j_per_slice = jps;
+    ctx->slices = (n + jps - 1) / jps;
+}
+
+}  // namespace
+
+extern "C" {
+
+void nbody_default_config(nbody_config* cfg)
+{
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->num_bodies = 10000;      // benchmark.cpp:302
+    cfg->spread = 400.0f;         // :303
+    cfg->mass = 1000.0f;          // :304
+    cfg->dt = 0.05f;              // :306
+    cfg->theta = 1.0f;            // :305
+    cfg->use_barnes_hut = 1;      // :300
+    cfg->use_parallel = 1;        // :301
+    cfg->ref_compat = 1;
+    cfg->device = -1;
+}
+
+int nbody_shard_range(int32_t n, int32_t nranks, int32_t rank, int32_t* begin, int32_t* count)
+{
+    if (n < 0 || nranks < 1 || rank < 0 || rank >= nranks || !begin || !count)
+        return fail(NBODY_ERR_INVALID, "nbody_shard_range: bad arguments (n=%d nranks=%d rank=%d)", n, nranks, rank);
+    // groups of 8 bodies (benchmark.cpp:421) are dealt out as evenly as possible; the N%8 tail
+    // (never a target in the reference) rides with the last rank.
+    const int64_t groups = n / 8;
+    const int64_t g0 = groups * rank / nranks, g1 = groups * (rank + 1) / nranks;
+    int64_t b = g0 * 8, e = g1 * 8;
+    if (rank == nranks - 1) e = n;
+    *begin = (int32_t)b;
+    *count = (int32_t)(e - b);
+    return NBODY_OK;
+}
+
+int nbody_create(const nbody_config* cfg, nbody_ctx** out)
+{
+    if (!cfg || !out) return fail(NBODY_ERR_INVALID, "nbody_create: null argument");
+    *out = nullptr;
+    const int n = cfg->num_bodies;
+    if (n < 1) return fail(NBODY_ERR_INVALID, "nbody_create: num_bodies=%d", n);
+    if (!(cfg->dt == cfg->dt)) return fail(NBODY_ERR_INVALID, "nbody_create: dt is NaN");
+    if (cfg->shard_begin < 0 || cfg->shard_count < 0 || (int64_t)cfg->shard_begin + cfg->shard_count > n)
+        return fail(NBODY_ERR_INVALID, "nbody_create: shard [%d,+%d) outside [0,%d)", cfg->shard_begin, cfg->shard_count, n);
+    if (cfg->force_variant < 0 || cfg->force_variant > 3)
+        return fail(NBODY_ERR_INVALID, "nbody_create: force_variant=%d", cfg->force_variant);
+    if (cfg->use_barnes_hut)
+        return fail(NBODY_ERR_UNSUPPORTED, "nbody_create: Barnes-Hut path not built yet");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(NBODY_ERR_NO_DEVICE, "nbody_create: no HIP device visible (there is no CPU fallback)");
+    int dev = cfg->device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    if (dev >= ndev) return fail(NBODY_ERR_NO_DEVICE, "nbody_create: device %d of %d", dev, ndev);
+    HIP_TRY(hipSetDevice(dev));
+
+    nbody_ctx* ctx = new (std::nothrow) nbody_ctx();
+    if (!ctx) return fail(NBODY_ERR_INVALID, "nbody_create: out of host memory");
+    ctx->cfg = *cfg;
+    ctx->device = dev;
+    const int sb = cfg->shard_begin;
+    const int sc = cfg->shard_count == 0 ? n - sb : cfg->shard_count;
+    const int lim = cfg->ref_compat ? n - (n % 8) : n;   // benchmark.cpp:423
+    ctx->i_begin = sb;
+    ctx->i_end = (sb + sc < lim) ? sb + sc : lim;
+    if (ctx->i_end < ctx->i_begin) ctx->i_end = ctx->i_begin;
+    ctx->i_stride = ((sc + 63) / 64) * 64;
+    if (ctx->i_stride < 64) ctx->i_stride = 64;
+    plan_force(ctx);
+
+    auto cleanup = [&](int code) { nbody_destroy(ctx); return code; };
+#define HIP_TRY_C(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return cleanup(fail(NBODY_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)));            \
+    } while (0)
+    HIP_TRY_C(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    const size_t nb = sizeof(float) * (size_t)n;
+    float** arrs[] = {&ctx->m, &ctx->px, &ctx->py, &ctx->vx, &ctx->vy, &ctx->radius, &ctx->c, &ctx->ax, &ctx->ay};
+    for (float** p : arrs) HIP_TRY_C(hipMalloc((void**)p, nb));
+    const size_t pb = sizeof(float) * (size_t)kMaxSlices * ctx->i_stride;
+    HIP_TRY_C(hipMalloc((void**)&ctx->pax, pb));
+    HIP_TRY_C(hipMalloc((void**)&ctx->pay, pb));
+    ctx->diag_blocks = (n + kDiagBlock - 1) / kDiagBlock;
+    HIP_TRY_C(hipMalloc((void**)&ctx->diag_partials, sizeof(double) * 5 * (size_t)ctx->diag_blocks));
+    HIP_TRY_C(hipMemset(ctx->ax, 0, nb));
+    HIP_TRY_C(hipMemset(ctx->ay, 0, nb));
+#undef HIP_TRY_C
+    *out = ctx;
+    return NBODY_OK;
+}
+
+void nbody_destroy(nbody_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    float* arrs[] = {ctx->m, ctx->px, ctx->py, ctx->vx, ctx->vy, ctx->radius, ctx->c, ctx->ax, ctx->ay, ctx->pax, ctx->pay};
+    for (float* p : arrs)
+        if (p) (void)hipFree(p);
+    if (ctx->diag_partials) (void)hipFree(ctx->diag_partials);
+    for (auto& pool : ctx->prof.pool)
+        for (auto& ep : pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int nbody_set_stream(nbody_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return fail(NBODY_ERR_INVALID, "nbody_set_stream: null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return NBODY_OK;
+}
+
+int nbody_upload(nbody_ctx* ctx, const float* m, const float* posX, const float* posY, const float* velX,
+                 const float* velY, const float* radius)
+{
+    if (!ctx || !m || !posX || !posY || !velX || !velY || !radius)
+        return fail(NBODY_ERR_INVALID, "nbody_upload: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int n = ctx->cfg.num_bodies;
+    // Choose the pair-formula variant from the data (see force_naive.hip.h for the conditions).
+    bool uni_m = true, uni_r = true, finite = true;
+    float rmin = radius[0];
+    for (int i = 0; i < n; ++i) {
+        uni_m &= (m[i] == m[0]);
+        uni_r &= (radius[i] == radius[0]);
+        rmin = radius[i] < rmin ? radius[i] : rmin;
+        finite &= std::isfinite(m[i]) && std::isfinite(radius[i]) && std::isfinite(posX[i]) && std::isfinite(posY[i]);
+    }
+    if (!finite) return fail(NBODY_ERR_INVALID, "nbody_upload: non-finite mass/radius/position");
+    int variant = ctx->cfg.force_variant;
+    const bool clamp_ok = rmin >= 4.0f;          // R^2 >= 16: inv^2 stands in for 1/(d2+1e-6) to < 1 ulp
+    if (variant == 0) variant = !clamp_ok ? kExact : (uni_m && uni_r ? kUniform : kPerBody);
+    if (variant == kUniform && !(uni_m && uni_r))
+        return fail(NBODY_ERR_INVALID, "nbody_upload: force_variant=uniform but m/radius arrays are not constant");
+    if ((variant == kUniform || variant == kPerBody) && !clamp_ok)
+        return fail(NBODY_ERR_INVALID, "nbody_upload: force_variant %d needs every radius >= 4 (min %g)", variant, rmin);
+    ctx->variant = variant;
+    ctx->uni_m = m[0];
+    ctx->uni_c = 1.0f / (radius[0] * radius[0] + kSoft2);
+    std::vector<float> c((size_t)n);
+    for (int i = 0; i < n; ++i)
+        c[i] = variant == kExact ? radius[i] * radius[i] : 1.0f / (radius[i] * radius[i] + kSoft2);
+
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const size_t nb = sizeof(float) * (size_t)n;
+    HIP_TRY(hipMemcpy(ctx->m, m, nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->px, posX, nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->py, posY, nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->vx, velX, nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->vy, velY, nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->radius, radius, nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->c, c.data(), nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(ctx->ax, 0, nb));
+    HIP_TRY(hipMemset(ctx->ay, 0, nb));
+    ctx->uploaded = true;
+    return NBODY_OK;
+}
+
+int nbody_step(nbody_ctx* ctx, int32_t nsteps)
+{
+    if (!ctx) return fail(NBODY_ERR_INVALID, "nbody_step: null context");
+    if (!ctx->uploaded) return fail(NBODY_ERR_INVALID, "nbody_step: nbody_upload has not been called");
+    if (nsteps < 0) return fail(NBODY_ERR_INVALID, "nbody_step: nsteps=%d", nsteps);
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (int s = 0; s < nsteps; ++s) {
+        int rc = enqueue_force(ctx);
+        if (rc) return rc;
+        rc = enqueue_integrate(ctx, 1);
+        if (rc) return rc;
+    }
+    return NBODY_OK;
+}
+
+int nbody_compute_accel(nbody_ctx* ctx)
+{
+    if (!ctx) return fail(NBODY_ERR_INVALID, "nbody_compute_accel: null context");
+    if (!ctx->uploaded) return fail(NBODY_ERR_INVALID, "nbody_compute_accel: nbody_upload has not been called");
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = enqueue_force(ctx);
+    if (rc) return rc;
+    return enqueue_integrate(ctx, 0);
+}
+
+int nbody_sync(nbody_ctx* ctx)
+{
+    if (!ctx) return fail(NBODY_ERR_INVALID, "nbody_sync: null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return NBODY_OK;
+}
+
+int nbody_download(nbody_ctx* ctx, float* posX, float* posY, float* velX, float* velY)
+{
+    if (!ctx) return fail(NBODY_ERR_INVALID, "nbody_download: null context");
+    if (!ctx->uploaded) return fail(NBODY_ERR_INVALID, "nbody_download: nothing uploaded");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const size_t nb = sizeof(float) * (size_t)ctx->cfg.num_bodies;
+    if (posX) HIP_TRY(hipMemcpy(posX, ctx->px, nb, hipMemcpyDeviceToHost));
+    if (posY) HIP_TRY(hipMemcpy(posY, ctx->py, nb, hipMemcpyDeviceToHost));
+    if (velX) HIP_TRY(hipMemcpy(velX, ctx->vx, nb, hipMemcpyDeviceToHost));
+    if (velY) HIP_TRY(hipMemcpy(velY, ctx->vy, nb, hipMemcpyDeviceToHost));
+    return NBODY_OK;
+}
+
+int nbody_get_accel(nbody_ctx* ctx, float* accX, float* accY)
+{
+    if (!ctx || !accX || !accY) return fail(NBODY_ERR_INVALID, "nbody_get_accel: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const size_t nb = sizeof(float) * (size_t)ctx->cfg.num_bodies;
+    HIP_TRY(hipMemcpy(accX, ctx->ax, nb, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(accY, ctx->ay, nb, hipMemcpyDeviceToHost));
+    return NBODY_OK;
+}
+
+int nbody_diagnostics(nbody_ctx* ctx, double out[5])
+{
+    if (!ctx || !out) return fail(NBODY_ERR_INVALID, "nbody_diagnostics: null argument");
+    if (!ctx->uploaded) return fail(NBODY_ERR_INVALID, "nbody_diagnostics: nothing uploaded");
+    HIP_TRY(hipSetDevice(ctx->device));
+    DiagArgs a{};
+    a.m = ctx->m; a.px = ctx->px; a.py = ctx->py; a.vx = ctx->vx; a.vy = ctx->vy; a.radius = ctx->radius;
+    a.n = ctx->cfg.num_bodies; a.partials = ctx->diag_partials;
+    diagnostics_kernel<<<dim3(ctx->diag_blocks), dim3(kDiagBlock), 0, ctx->stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<double> h((size_t)5 * ctx->diag_blocks);
+    HIP_TRY(hipMemcpy(h.data(), ctx->diag_partials, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 5; ++k) out[k] = 0.0;
+    for (int b = 0; b < ctx->diag_blocks; ++b)
+        for (int k = 0; k < 5; ++k) out[k] += h[(size_t)b * 5 + k];
+    return NBODY_OK;
+}
+
+void* nbody_device_ptr(nbody_ctx* ctx, int32_t which)
+{
+    if (!ctx) { fail(NBODY_ERR_INVALID, "nbody_device_ptr: null context"); return nullptr; }
+    float* t[] = {ctx->m, ctx->px, ctx->py, ctx->vx, ctx->vy, ctx->radius, ctx->ax, ctx->ay};
+    if (which < 0 || which > 7) { fail(NBODY_ERR_INVALID, "nbody_device_ptr: which=%d", which); return nullptr; }
+    return t[which];
+}
+
+int nbody_profile_enable(nbody_ctx* ctx, int32_t on)
+{
+    if (!ctx) return fail(NBODY_ERR_INVALID, "nbody_profile_enable: null context");
+    ctx->prof.on = on != 0;
+    return NBODY_OK;
+}
+
+int nbody_profile_read(nbody_ctx* ctx, int32_t which, double* total_ms, int64_t* launches)
+{
+    if (!ctx || which < 0 || which > 2) return fail(NBODY_ERR_INVALID, "nbody_profile_read: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    Profiler& p = ctx->prof;
+    for (size_t i = 0; i < p.used[which]; ++i) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, p.pool[which][i].a, p.pool[which][i].b));
+        p.total_ms[which] += ms;
+    }
+    p.used[which] = 0;
+    if (total_ms) *total_ms = p.total_ms[which];
+    if (launches) *launches = p.launches[which];
+    return NBODY_OK;
+}
+
+int nbody_profile_reset(nbody_ctx* ctx)
+{
+    if (!ctx) return fail(NBODY_ERR_INVALID, "nbody_profile_reset: null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 3; ++k) { ctx->prof.used[k] = 0; ctx->prof.total_ms[k] = 0; ctx->prof.launches[k] = 0; }
+    return NBODY_OK;
+}
+
+int nbody_get_info(nbody_ctx* ctx, int32_t* force_variant, int32_t* j_slices, int32_t* blocks)
+{
+    if (!ctx) return fail(NBODY_ERR_INVALID, "nbody_get_info: null context");
+    if (force_variant) *force_variant = ctx->variant;
+    if (j_slices) *j_slices = ctx->slices;
+    if (blocks) *blocks = ctx->blocks_x;
+    return NBODY_OK;
+}
+
+int64_t nbody_bh_tree_nodes(nbody_ctx* ctx, void* out, int64_t cap)
+{
+    (void)ctx; (void)out; (void)cap;
+    return fail(NBODY_ERR_UNSUPPORTED, "nbody_bh_tree_nodes: Barnes-Hut path not built yet");
+}
+
+int nbody_bh_counters(nbody_ctx* ctx, int64_t out[2])
+{
+    (void)ctx; (void)out;
+    return fail(NBODY_ERR_UNSUPPORTED, "nbody_bh_counters: Barnes-Hut path not built yet");
+}
+
+const char* nbody_last_error(void) { return g_err; }
+
+int nbody_abi_version(void) { return NBODY_ABI_VERSION; }
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+"""Multi-GPU step driver: one process per GPU, i-bodies sharded, positions all-gathered each step.
+
+SURVEY.md §8e (no reference counterpart — the reference is a single OpenMP process).  Each rank owns the
+contiguous target range ``nbody_shard_range(N, world, rank)``; every rank holds ALL positions (they are the
+sources of the pair loop) and after each local step the owned slices of posX/posY are exchanged with ONE
+collective per array over ``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU
+tests).  Velocities and accelerations stay rank-local; m and radius are constant and uploaded everywhere.
+Message size per GPU per step: 8 B x N/P sent, 8 B x N x (P-1)/P received (7 MiB at N=2^20, P=8).
+
+torch is plumbing here (process group, stream ordering); the physics runs in the C-ABI library.
+"""
+import numpy as np
+
+
+def exchange_slices(tensors, spans, rank, dist, group=None):
+    """All-gather in place: every rank contributes tensors[k][begin:begin+count] of ITS span.
+
+    Equal spans -> one all_gather_into_tensor per array (in place, the input is a view of the output);
+    ragged spans (N not divisible) -> one broadcast per rank and array."""
+    counts = {c for _, c in spans}
+    if len(counts) == 1 and spans[0][1] * len(spans) == tensors[0].numel():
+        b, c = spans[rank]
+        for t in tensors:
+            dist.all_gather_into_tensor(t, t[b:b + c], group=group)
+    else:
+        for src, (b, c) in enumerate(spans):
+            if c == 0:
+                continue
+            for t in tensors:
+                dist.broadcast(t[b:b + c], src=src, group=group)
+
+
+class ShardedNaiveSim:
+    """One rank's share of a sharded naive simulation on its GPU."""
+
+    def __init__(self, pkg, num_bodies, rank, world, *, device, dt=0.05, ref_compat=True, dist=None, **kw):
+        import torch
+        self.torch, self.dist = torch, dist
+        self.rank, self.world, self.n = rank, world, num_bodies
+        self.spans = [pkg.shard_range(num_bodies, world, r) for r in range(world)]
+        self.sim = pkg.NBodySim(num_bodies, dt=dt, useBarnesHut=False, ref_compat=ref_compat, device=device,
+                                shard=self.spans[rank], **kw)
+        self.device = torch.device("cuda", device)
+        # order the library's kernels and torch's collectives on the same stream
+        self.sim.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self._pos = None
+
+    def upload(self, m, posX, posY, velX, velY, radius):
+        self.sim.upload(m, posX, posY, velX, velY, radius)
+        t = self.torch
+        self._pos = [t.as_tensor(self.sim.device_array(k), device=self.device) for k in ("posX", "posY")]
+        return self
+
+    def step(self, nsteps=1):
+        for _ in range(nsteps):
+            self.sim.step(1)                               # force over all sources + Euler on the owned shard
+            if self.world > 1:
+                exchange_slices(self._pos, self.spans, self.rank, self.dist)
+        return self
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+    def targets(self):
+        return self.spans[self.rank]
+
+    def close(self):
+        self._pos = None
+        self.sim.close()
+
+
+def owned_targets(num_bodies, spans, rank, ref_compat=True):
+    """Number of bodies rank actually advances (the N%8 tail is frozen in ref_compat, benchmark.cpp:423)."""
+    b, c = spans[rank]
+    lim = num_bodies - num_bodies % 8 if ref_compat else num_bodies
+    return max(0, min(b + c, lim) - b)
+
+
+def to_numpy(t):
+    return t.detach().cpu().numpy().astype(np.float32, copy=False)

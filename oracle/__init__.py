@@ -1,0 +1,262 @@
+"""TEST INFRASTRUCTURE — ctypes bindings for the CPU oracle and the compiled reference.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package, and only as the checker.  The product package (``n-body_amd``) never does.
+
+* ``libnbody_oracle.so``      — oracle/nbody_oracle.c, the plain-C restatement.
+* ``_ref/libnbody_ref.so``    — /root/reference/benchmark.cpp itself, compiled by build_ref.sh.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(_HERE, "libnbody_oracle.so")
+REF_SO = os.path.join(_HERE, "_ref", "libnbody_ref.so")
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+
+NODE_DTYPE = np.dtype([("mass", "f4"), ("comX", "f4"), ("comY", "f4"),
+                       ("tlX", "f4"), ("tlY", "f4"), ("brX", "f4"), ("brY", "f4"),
+                       ("bodyIndex", "i4"), ("children", "i4", (4,))])
+assert NODE_DTYPE.itemsize == 48
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(ORACLE_SO)
+        L.oracle_mt19937_uniform01.argtypes = [C.c_uint32, C.c_int, _f32p]
+        L.oracle_mt19937_raw.argtypes = [C.c_uint32, C.c_int, np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")]
+        L.oracle_init_disc.argtypes = [C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_float] + [_f32p] * 6
+        L.oracle_naive_accel_f64.argtypes = [C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, _f64p, _f64p]
+        L.oracle_naive_accel_f64_range.argtypes = [C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, _f64p, _f64p]
+        L.oracle_naive_accel_f64_subset.argtypes = [C.c_int, _f32p, _f32p, _f32p, _f32p, _i32p, C.c_int, _f64p, _f64p]
+        L.oracle_naive_accel_f32.argtypes = [C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, _f32p]
+        L.oracle_euler_f32.argtypes = [C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_int]
+        L.oracle_naive_steps.argtypes = [C.c_int] + [_f32p] * 6 + [C.c_float, C.c_int, C.c_int]
+        L.oracle_diagnostics.argtypes = [C.c_int] + [_f32p] * 6 + [_f64p]
+        L.oracle_tree_create.restype = C.c_void_p
+        L.oracle_tree_create.argtypes = [C.c_int]
+        L.oracle_tree_destroy.argtypes = [C.c_void_p]
+        L.oracle_tree_build.argtypes = [C.c_void_p, C.c_int, C.c_float, _f32p, _f32p, _f32p]
+        L.oracle_tree_nodes_used.argtypes = [C.c_void_p]
+        L.oracle_tree_pool.restype = C.c_void_p
+        L.oracle_tree_pool.argtypes = [C.c_void_p]
+        L.oracle_tree_stats.argtypes = [C.c_void_p, _i32p]
+        L.oracle_bh_accel.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, _f32p, C.c_float, C.c_int, C.c_int,
+                                      _f64p, _f64p, _i64p]
+        L.oracle_bh_steps.argtypes = [C.c_int] + [_f32p] * 6 + [C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
+        _lib = L
+    return _lib
+
+
+class Bodies:
+    """SoA state with the reference's field names (benchmark.cpp:24-49)."""
+    FIELDS = ("m", "posX", "posY", "velX", "velY", "radius")
+
+    def __init__(self, n):
+        self.n = n
+        for f in self.FIELDS:
+            setattr(self, f, np.zeros(n, np.float32))
+
+    def copy(self):
+        b = Bodies(self.n)
+        for f in self.FIELDS:
+            setattr(b, f, getattr(self, f).copy())
+        return b
+
+    def arrays(self):
+        return [getattr(self, f) for f in self.FIELDS]
+
+
+def init_disc(n, spread=400.0, mass=1000.0, seed=12345, vel_factor=0.3):
+    b = Bodies(n)
+    lib().oracle_init_disc(n, spread, mass, seed, vel_factor, *b.arrays())
+    return b
+
+
+def init_plummer(n, scale=50.0, mass=1000.0, seed=12345, rmax_factor=20.0):
+    """2-D Plummer-like clustered disc (BASELINE config 5).  The reference has NO such generator
+    (SURVEY.md §0); this one is defined by the build: surface density ∝ (1+r²/a²)^-2 =>
+    r = a·sqrt(u/(1-u)) truncated at rmax_factor·a, circular-ish tangential velocities."""
+    rng = np.random.default_rng(seed)
+    u = rng.random(n)
+    umax = rmax_factor ** 2 / (1.0 + rmax_factor ** 2)
+    u = u * umax
+    r = scale * np.sqrt(u / (1.0 - u))
+    phi = rng.random(n) * 2 * np.pi
+    b = Bodies(n)
+    b.m[:] = mass
+    b.radius[:] = 8.0
+    b.posX[:] = (r * np.cos(phi)).astype(np.float32)
+    b.posY[:] = (r * np.sin(phi)).astype(np.float32)
+    menc = mass * n * (r ** 2 / (r ** 2 + scale ** 2))
+    v = np.sqrt(menc / np.maximum(r, 1.0)) * 0.3
+    b.velX[:] = (-np.sin(phi) * v).astype(np.float32)
+    b.velY[:] = (np.cos(phi) * v).astype(np.float32)
+    return b
+
+
+def naive_accel_f64(b, ref_compat=1):
+    ax = np.zeros(b.n); ay = np.zeros(b.n)
+    lib().oracle_naive_accel_f64(b.n, b.m, b.posX, b.posY, b.radius, ref_compat, ax, ay)
+    return ax, ay
+
+
+def naive_accel_f64_range(b, i0, i1):
+    """Accelerations of targets [i0, i1) against all sources (one rank's shard)."""
+    ax = np.zeros(max(i1 - i0, 0)); ay = np.zeros(max(i1 - i0, 0))
+    if i1 > i0:
+        lib().oracle_naive_accel_f64_range(b.n, b.m, b.posX, b.posY, b.radius, i0, i1, ax, ay)
+    return ax, ay
+
+
+def naive_accel_f64_subset(b, idx):
+    idx = np.ascontiguousarray(idx, np.int32)
+    ax = np.zeros(len(idx)); ay = np.zeros(len(idx))
+    lib().oracle_naive_accel_f64_subset(b.n, b.m, b.posX, b.posY, b.radius, idx, len(idx), ax, ay)
+    return ax, ay
+
+
+def naive_accel_f32(b, ref_compat=1):
+    ax = np.zeros(b.n, np.float32); ay = np.zeros(b.n, np.float32)
+    lib().oracle_naive_accel_f32(b.n, b.m, b.posX, b.posY, b.radius, ref_compat, ax, ay)
+    return ax, ay
+
+
+def naive_steps(b, dt, nsteps, ref_compat=1):
+    """In-place nsteps of f64-force + f32 Euler."""
+    lib().oracle_naive_steps(b.n, *b.arrays(), dt, nsteps, ref_compat)
+    return b
+
+
+def diagnostics(b):
+    out = np.zeros(5)
+    lib().oracle_diagnostics(b.n, *b.arrays(), out)
+    return out
+
+
+class Tree:
+    def __init__(self, n):
+        self.n = n
+        self.h = lib().oracle_tree_create(n)
+
+    def build(self, b, spread):
+        lib().oracle_tree_build(self.h, b.n, spread, b.m, b.posX, b.posY)
+        return self
+
+    @property
+    def nodes_used(self):
+        return lib().oracle_tree_nodes_used(self.h)
+
+    def pool(self):
+        n = self.nodes_used
+        buf = (C.c_char * (48 * n)).from_address(lib().oracle_tree_pool(self.h))
+        return np.frombuffer(buf, dtype=NODE_DTYPE, count=n).copy()
+
+    def stats(self):
+        out = np.zeros(4, np.int32)
+        lib().oracle_tree_stats(self.h, out)
+        return dict(nodes=int(out[0]), depth=int(out[1]), leaves=int(out[2]), bodies=int(out[3]))
+
+    def accel(self, b, theta, f64=False, group_size=8):
+        ax = np.zeros(b.n); ay = np.zeros(b.n); cnt = np.zeros(2, np.int64)
+        lib().oracle_bh_accel(self.h, b.n, b.posX, b.posY, b.radius, theta, int(f64), group_size, ax, ay, cnt)
+        return ax, ay, dict(visits=int(cnt[0]), accepts=int(cnt[1]))
+
+    def __del__(self):
+        try:
+            lib().oracle_tree_destroy(self.h)
+        except Exception:
+            pass
+
+
+def bh_steps(b, spread, theta, dt, nsteps, use_parallel=1):
+    lib().oracle_bh_steps(b.n, *b.arrays(), spread, theta, dt, nsteps, use_parallel)
+    return b
+
+
+# ---------------------------------------------------------------------------------------------
+# The reference itself (oracle/_ref/libnbody_ref.so)
+# ---------------------------------------------------------------------------------------------
+class _RefIO(C.Structure):
+    _fp = C.POINTER(C.c_float)
+    _fields_ = ([("use_barnes_hut", C.c_int), ("use_parallel", C.c_int), ("n", C.c_int),
+                 ("spread", C.c_float), ("mass", C.c_float), ("theta", C.c_float), ("dt", C.c_float),
+                 ("seed", C.c_uint), ("nsteps", C.c_int), ("log_enabled", C.c_int)]
+                + [(k, C.POINTER(C.c_float)) for k in ("in_m", "in_px", "in_py", "in_vx", "in_vy", "in_radius")]
+                + [(k, C.POINTER(C.c_float)) for k in ("init_m", "init_px", "init_py", "init_vx", "init_vy", "init_radius")]
+                + [(k, C.POINTER(C.c_float)) for k in ("out_px", "out_py", "out_vx", "out_vy", "acc_x", "acc_y")]
+                + [("tree_nodes_used", C.POINTER(C.c_int)), ("tree_root", C.POINTER(C.c_float)),
+                   ("tree_pool_out", C.c_void_p), ("tree_pool_cap", C.c_int),
+                   ("step_ms", C.POINTER(C.c_double))])
+
+
+_ref = None
+
+
+def ref_available():
+    return os.path.exists(REF_SO)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def ref_run(n, *, use_barnes_hut, nsteps, bodies=None, seed=12345, spread=400.0, mass=1000.0, theta=1.0,
+            dt=0.05, use_parallel=1, want_pool=False):
+    """Run the compiled reference loop (benchmark.cpp:349-557) for nsteps.
+
+    bodies=None -> the reference's own generator (benchmark.cpp:317-339) with `seed`.
+    Returns dict(init=Bodies, final=Bodies, acc=(ax, ay) of the last step, nodes_used, root, pool, step_ms)."""
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(REF_SO)
+        _ref.ref_benchmark_run.argtypes = [C.POINTER(_RefIO)]
+        _ref.ref_benchmark_run.restype = C.c_int
+    io = _RefIO()
+    io.use_barnes_hut, io.use_parallel, io.n = int(use_barnes_hut), int(use_parallel), n
+    io.spread, io.mass, io.theta, io.dt = spread, mass, theta, dt
+    io.seed, io.nsteps, io.log_enabled = seed, nsteps, 0
+    keep = []
+    if bodies is not None:
+        src = bodies.copy()
+        keep.append(src)
+        io.in_m, io.in_px, io.in_py = _fp(src.m), _fp(src.posX), _fp(src.posY)
+        io.in_vx, io.in_vy, io.in_radius = _fp(src.velX), _fp(src.velY), _fp(src.radius)
+    init = Bodies(n)
+    io.init_m, io.init_px, io.init_py = _fp(init.m), _fp(init.posX), _fp(init.posY)
+    io.init_vx, io.init_vy, io.init_radius = _fp(init.velX), _fp(init.velY), _fp(init.radius)
+    final = Bodies(n)
+    io.out_px, io.out_py, io.out_vx, io.out_vy = _fp(final.posX), _fp(final.posY), _fp(final.velX), _fp(final.velY)
+    ax = np.zeros(n, np.float32); ay = np.zeros(n, np.float32)
+    io.acc_x, io.acc_y = _fp(ax), _fp(ay)
+    used = C.c_int(0)
+    root = np.zeros(3, np.float32)
+    io.tree_nodes_used = C.pointer(used)
+    io.tree_root = _fp(root)
+    pool = None
+    if want_pool:
+        cap = max(8, 32 * n)
+        pool = np.zeros(cap, NODE_DTYPE)
+        io.tree_pool_out = pool.ctypes.data
+        io.tree_pool_cap = cap
+    ms = np.zeros(max(nsteps, 1))
+    io.step_ms = ms.ctypes.data_as(C.POINTER(C.c_double))
+    rc = _ref.ref_benchmark_run(C.byref(io))
+    if rc != 0:
+        raise RuntimeError(f"ref_benchmark_run returned {rc}")
+    srcb = bodies if bodies is not None else init
+    final.m[:] = srcb.m
+    final.radius[:] = srcb.radius
+    if pool is not None:
+        pool = pool[:used.value].copy()
+    return dict(init=init, final=final, acc=(ax, ay), nodes_used=used.value, root=root, pool=pool,
+                step_ms=ms[:nsteps])

@@ -1,0 +1,187 @@
+"""CPU tests of the boundary: the C-ABI library loads, exports every symbol include/nbody.h declares,
+its pure-host entry points behave, and (without a GPU) creation fails loudly instead of falling back."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_all_exported(nb):
+    hdr = open(os.path.join(ROOT, "include", "nbody.h")).read()
+    declared = set(re.findall(r"\b(nbody_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"nbody_config", "nbody_ctx"}
+    assert declared == set(nb.ABI_SYMBOLS)
+    raw = C.CDLL(nb.LIB_PATH)
+    for s in declared:
+        assert hasattr(raw, s), f"{s} declared in include/nbody.h but not exported"
+    assert nb.lib().nbody_abi_version() == 1
+
+
+def test_default_config_matches_reference_literals(nb):
+    cfg = nb.default_config()       # benchmark.cpp:300-306
+    assert (cfg.use_barnes_hut, cfg.use_parallel, cfg.num_bodies) == (1, 1, 10000)
+    assert (cfg.spread, cfg.mass, cfg.theta) == (400.0, 1000.0, 1.0)
+    assert abs(cfg.dt - 0.05) < 1e-9
+    assert C.sizeof(nb.Config) == 64
+
+
+@pytest.mark.parametrize("n,p", [(1 << 20, 8), (10000, 8), (1003, 4), (65536, 3), (17, 8), (8, 2), (5, 2)])
+def test_shard_range_partitions(nb, n, p):
+    spans = [nb.shard_range(n, p, r) for r in range(p)]
+    pos = 0
+    for b, c in spans:
+        assert b == pos and c >= 0
+        pos += c
+    assert pos == n
+    for b, c in spans[:-1]:
+        assert b % 8 == 0 and c % 8 == 0          # groups of 8 (benchmark.cpp:421) never straddle GPUs
+    counts = [c for _, c in spans[:-1]] or [0]
+    assert max(counts) - min(counts) <= 8
+
+
+def test_shard_range_rejects_bad_arguments(nb):
+    with pytest.raises(nb.NBodyError):
+        nb.shard_range(100, 0, 0)
+    with pytest.raises(nb.NBodyError):
+        nb.shard_range(100, 4, 4)
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_create_validates_and_never_falls_back(nb):
+    with pytest.raises(nb.NBodyError) as e:
+        nb.NBodySim(0)
+    assert e.value.code == nb.ERR_INVALID
+    with pytest.raises(nb.NBodyError) as e:
+        nb.NBodySim(100, shard=(90, 20))
+    assert e.value.code == nb.ERR_INVALID
+    if not _have_gpu():
+        with pytest.raises(nb.NBodyError) as e:
+            nb.NBodySim(1024)
+        assert e.value.code == nb.ERR_NO_DEVICE
+        assert "no CPU fallback" in str(e.value)
+
+
+def test_host_benchmark_binary_fails_loudly_without_gpu():
+    exe = os.path.join(ROOT, "n-body_amd", "bin", "nbody_benchmark")
+    if not os.path.exists(exe):
+        pytest.skip("host drivers not built")
+    if _have_gpu():
+        pytest.skip("GPU present")
+    r = subprocess.run([exe, "--n", "256", "--naive", "--steps", "1", "--no-log"], capture_output=True, text=True)
+    assert r.returncode != 0 and "no HIP device" in r.stderr
+
+
+# ---------------------------------------------------------------------------------------------------
+# config.json reader (host/config_reader.hpp) — semantics of main.cpp:348-398, exercised through a tiny
+# C++ probe compiled on the fly with g++ (host-only code, no GPU).
+# ---------------------------------------------------------------------------------------------------
+PROBE = r'''
+#include "config_reader.hpp"
+#include <cstdio>
+int main(int argc, char** argv) {
+    nbody_host::SimConfig c = nbody_host::load_config(argc > 1 ? argv[1] : "config.json", false);
+    std::printf("%d %d %d %d %g %g %g %g %d|%s\n", (int)c.loaded, (int)c.useBarnesHut, (int)c.useParallel, c.numBodies,
+                c.spread, c.mass, c.theta, c.dt, c.windowSize, c.windowTitle.c_str());
+    return 0;
+}
+'''
+
+
+@pytest.fixture(scope="module")
+def probe(tmp_path_factory):
+    d = tmp_path_factory.mktemp("cfgprobe")
+    src = d / "probe.cpp"
+    src.write_text(PROBE)
+    exe = d / "probe"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "n-body_amd", "host"), str(src), "-o", str(exe)],
+                   check=True)
+    return exe
+
+
+def run_probe(probe, cwd, text, name="config.json"):
+    if text is not None:
+        (cwd / name).write_text(text)
+    out = subprocess.run([str(probe), name], cwd=str(cwd), capture_output=True, text=True, check=True).stdout.strip()
+    head, title = out.split("|", 1)
+    v = head.split()
+    return dict(loaded=int(v[0]), bh=int(v[1]), par=int(v[2]), n=int(v[3]), spread=float(v[4]), mass=float(v[5]),
+                theta=float(v[6]), dt=float(v[7]), window=int(v[8]), title=title)
+
+
+REFERENCE_CONFIG = '''{
+  "simulation": {
+    "useBarnesHut": true,
+    "useParallel": true,
+    "numBodies": 10000,
+    "spread": 400.0,
+    "mass": 1000.0,
+    "theta": 1.0,
+    "dt": 0.03
+  },
+  "display": {
+    "windowSize": 1000,
+    "windowTitle": "Chaotic N-Body Simulation"
+  }
+}
+'''
+
+
+def test_config_reader_reference_file(probe, tmp_path):
+    c = run_probe(probe, tmp_path, REFERENCE_CONFIG)      # same key/values as the reference's config.json:1-15
+    assert c == dict(loaded=1, bh=1, par=1, n=10000, spread=400.0, mass=1000.0, theta=1.0, dt=0.03, window=1000,
+                     title="Chaotic N-Body Simulation")
+
+
+def test_config_reader_defaults_when_missing(probe, tmp_path):
+    c = run_probe(probe, tmp_path, None, name="absent.json")   # main.cpp:337-345
+    assert (c["loaded"], c["bh"], c["par"], c["n"], c["dt"], c["window"]) == (0, 1, 1, 50000, 0.03, 1000)
+
+
+def test_config_reader_flat_and_quirks(probe, tmp_path):
+    # flat layout (README.md:113-125 style), naive mode, and the untrimmed-boolean quirk (main.cpp:384-385):
+    # `true }` with a blank before the brace is NOT "true".
+    c = run_probe(probe, tmp_path, '{ "useBarnesHut": false, "numBodies": 65536 , "dt": 0.05, "useParallel": true }')
+    assert (c["bh"], c["n"], c["dt"], c["par"]) == (0, 65536, 0.05, 0)
+    c = run_probe(probe, tmp_path, '{"useParallel": true}')
+    assert c["par"] == 1
+
+
+def test_config_reader_searches_parent_dirs(probe, tmp_path):
+    (tmp_path / "config.json").write_text('{"numBodies": 4242}')
+    deep = tmp_path / "build" / "bin"
+    deep.mkdir(parents=True)
+    assert run_probe(probe, deep, None)["n"] == 4242       # cwd/../.. (main.cpp:41)
+    deeper = deep / "x"
+    deeper.mkdir()
+    assert run_probe(probe, deeper, None)["loaded"] == 0    # three levels up is not searched
+
+
+def test_host_generator_matches_oracle(O, tmp_path):
+    """host/initial_conditions.hpp (used by the C++ drivers) == oracle generator == reference generator."""
+    src = tmp_path / "gen.cpp"
+    src.write_text(r'''
+#include "initial_conditions.hpp"
+#include <cstdio>
+int main() { nbody_host::BodyStore b; nbody_host::fill_disc(b, 1024, 400.0f, 1000.0f, 12345u, 0.3f);
+  std::fwrite(b.posX.data(), 4, 1024, stdout); std::fwrite(b.posY.data(), 4, 1024, stdout);
+  std::fwrite(b.velX.data(), 4, 1024, stdout); std::fwrite(b.velY.data(), 4, 1024, stdout); return 0; }
+''')
+    exe = tmp_path / "gen"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "n-body_amd", "host"), str(src), "-o", str(exe)], check=True)
+    raw = subprocess.run([str(exe)], capture_output=True, check=True).stdout
+    a = np.frombuffer(raw, np.float32).reshape(4, 1024)
+    b = O.init_disc(1024, seed=12345)
+    assert np.array_equal(a[0], b.posX) and np.array_equal(a[1], b.posY)
+    assert np.allclose(a[2], b.velX, rtol=1e-6, atol=1e-7) and np.allclose(a[3], b.velY, rtol=1e-6, atol=1e-7)

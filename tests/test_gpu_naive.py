@@ -1,0 +1,295 @@
+"""GPU parity tests for the naive O(N^2) path, through the C-ABI.
+
+Gates: the reference's -ffast-math build is the inaccurate party (12-bit vrcpps), so
+  * GPU vs the f64 oracle:            max per-body relative error <= 1e-4   (expected ~1e-6)
+  * GPU vs the compiled reference:    median <= 5e-5, p99 <= 3e-4 at N >= 10000 (1e-4 / 1e-3 at N ~ 1000)
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_F64 = 1e-4
+
+
+def run_gpu(nb, b, *, nsteps=0, dt=0.05, **kw):
+    with nb.NBodySim(b.n, dt=dt, useBarnesHut=False, **kw) as sim:
+        sim.upload(*b.arrays())
+        if nsteps == 0:
+            sim.compute_accel()
+        else:
+            sim.step(nsteps)
+        ax, ay = sim.accel()
+        st = sim.download()
+        info = sim.info()
+    return ax, ay, st, info
+
+
+@pytest.mark.parametrize("name", ["naive_n1024", "naive_n1003", "naive_n10000"])
+def test_accel_vs_oracle_and_reference(nb, O, name):
+    g, b = load_golden(O, name)
+    lim = b.n - b.n % 8
+    ax, ay, _, info = run_gpu(nb, b)
+    assert info["force_variant"] == 1          # reference data: uniform mass and radius 8
+    rx, ry = O.naive_accel_f64(b)
+    e = rel_err(ax[:lim], ay[:lim], rx[:lim], ry[:lim])
+    assert e.max() <= TOL_F64, e.max()
+    e = rel_err(ax[:lim], ay[:lim], g["accX"][:lim], g["accY"][:lim])
+    med, p99 = (5e-5, 3e-4) if b.n >= 10000 else (1e-4, 1e-3)
+    assert np.median(e) <= med and np.percentile(e, 99) <= p99
+    assert np.all(ax[lim:] == 0) and np.all(ay[lim:] == 0)      # tail never a target (benchmark.cpp:423)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_all_force_variants_on_reference_data(nb, O, variant):
+    _, b = load_golden(O, "naive_n10000")
+    ax, ay, _, info = run_gpu(nb, b, force_variant=variant)
+    assert info["force_variant"] == variant
+    rx, ry = O.naive_accel_f64(b)
+    assert rel_err(ax, ay, rx, ry).max() <= TOL_F64
+
+
+def test_per_body_mass_and_radius(nb, O):
+    b = O.init_disc(4096, seed=99)
+    rng = np.random.default_rng(5)
+    b.m[:] = rng.uniform(10.0, 3000.0, b.n).astype(np.float32)
+    b.radius[:] = rng.uniform(4.0, 30.0, b.n).astype(np.float32)
+    ax, ay, _, info = run_gpu(nb, b)
+    assert info["force_variant"] == 2
+    rx, ry = O.naive_accel_f64(b)
+    assert rel_err(ax, ay, rx, ry).max() <= TOL_F64
+
+
+def test_small_radii_select_exact_variant(nb, O):
+    """radius < 4 breaks the inv^2 ~ 1/(d2+1e-6) shortcut; upload must pick the exact variant."""
+    b = O.init_disc(4096, seed=11)
+    b.posX *= 0.01; b.posY *= 0.01            # crowd: separations ~0.01..8
+    rng = np.random.default_rng(6)
+    b.radius[:] = rng.uniform(0.001, 0.5, b.n).astype(np.float32)
+    b.m[:] = rng.uniform(1.0, 10.0, b.n).astype(np.float32)
+    ax, ay, _, info = run_gpu(nb, b)
+    assert info["force_variant"] == 3
+    rx, ry = O.naive_accel_f64(b)
+    assert rel_err(ax, ay, rx, ry).max() <= TOL_F64
+    with pytest.raises(nb.NBodyError):
+        run_gpu(nb, b, force_variant=2)
+
+
+def test_crowded_clamp_branch(nb, O):
+    """Every pair inside the clamp radius (d < R = 8): exercises the min() branch exclusively."""
+    b = O.init_disc(2048, seed=21)
+    b.posX *= 0.005; b.posY *= 0.005
+    ax, ay, _, _ = run_gpu(nb, b)
+    rx, ry = O.naive_accel_f64(b)
+    assert rel_err(ax, ay, rx, ry).max() <= TOL_F64
+
+
+def test_coincident_bodies_and_self_pairs_are_masked(nb, O):
+    """d2 == 0 pairs contribute nothing (benchmark.cpp:468-472): duplicates of a body must not produce NaN."""
+    b = O.init_disc(1024, seed=4)
+    b.posX[1::2] = b.posX[0::2]; b.posY[1::2] = b.posY[0::2]     # every body has an exact twin
+    ax, ay, _, _ = run_gpu(nb, b)
+    assert np.all(np.isfinite(ax)) and np.all(np.isfinite(ay))
+    rx, ry = O.naive_accel_f64(b)
+    assert rel_err(ax, ay, rx, ry).max() <= TOL_F64
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 63, 64, 65, 255, 1025, 2049, 3000])
+def test_ragged_sizes(nb, O, n):
+    b = O.init_disc(n, seed=n)
+    for compat in (True, False):
+        ax, ay, st, _ = run_gpu(nb, b, nsteps=1, ref_compat=compat)
+        rx, ry = O.naive_accel_f64(b, ref_compat=int(compat))
+        lim = n - n % 8 if compat else n
+        if lim > 1:
+            assert rel_err(ax[:lim], ay[:lim], rx[:lim], ry[:lim]).max() <= TOL_F64
+        assert np.all(ax[lim:] == 0)
+        c = b.copy()
+        O.naive_steps(c, 0.05, 1, ref_compat=int(compat))
+        for k in ("posX", "posY", "velX", "velY"):
+            ref = getattr(c, k)
+            assert np.abs(st[k] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), k
+        # frozen tail (benchmark.cpp:486)
+        assert np.array_equal(st["posX"][lim:], b.posX[lim:]) and np.array_equal(st["velX"][lim:], b.velX[lim:])
+
+
+@pytest.mark.parametrize("name", ["naive_n1024", "naive_n1003", "naive_n10000"])
+def test_short_trajectory_vs_reference(nb, O, name):
+    g, b = load_golden(O, name)
+    _, _, st, _ = run_gpu(nb, b, nsteps=int(g["nsteps_final"]), dt=float(g["dt"]))
+    for k in ("posX", "posY"):
+        assert np.abs(st[k] - g["final_" + k]).max() <= 2e-5 * 400.0
+    for k in ("velX", "velY"):
+        assert np.abs(st[k] - g["final_" + k]).max() <= 2e-4 * np.abs(g["final_" + k]).max()
+    # and one step against the reference's own step-1 state
+    _, _, st, _ = run_gpu(nb, b, nsteps=1, dt=float(g["dt"]))
+    for k in ("posX", "posY", "velX", "velY"):
+        assert np.abs(st[k] - g["step1_" + k]).max() <= 2e-4 * max(1.0, np.abs(g["step1_" + k]).max())
+
+
+def test_euler_uses_old_values(nb, O):
+    """pos += v_old*dt and vel += a(pos_old)*dt (forward Euler, benchmark.cpp:497-503), not symplectic."""
+    b = O.init_disc(512, seed=8)
+    ax, ay, st, _ = run_gpu(nb, b, nsteps=1, dt=0.05)
+    assert np.allclose(st["posX"], b.posX + b.velX * np.float32(0.05), rtol=0, atol=1e-4)
+    assert np.allclose(st["velX"], b.velX + ax * np.float32(0.05), rtol=1e-6, atol=1e-4)
+
+
+def test_step_equals_compute_then_manual_euler_multi(nb, O):
+    """nbody_step(3) == 3 x nbody_step(1): enqueue-many and enqueue-one agree bit for bit."""
+    b = O.init_disc(3000, seed=12)
+    _, _, s3, _ = run_gpu(nb, b, nsteps=3)
+    with nb.NBodySim(b.n, dt=0.05, useBarnesHut=False) as sim:
+        sim.upload(*b.arrays())
+        for _ in range(3):
+            sim.step(1)
+        s1 = sim.download()
+    for k in s3:
+        assert np.array_equal(s3[k], s1[k])
+
+
+def test_n65536_sampled_vs_f64(nb, O):
+    """BASELINE config 2 size; f64 oracle on 2048 sampled targets (full f64 would take ~40 s)."""
+    b = O.init_disc(65536, seed=12345)
+    ax, ay, _, info = run_gpu(nb, b)
+    idx = np.arange(0, b.n, 32, dtype=np.int32)
+    rx, ry = O.naive_accel_f64_subset(b, idx)
+    e = rel_err(ax[idx], ay[idx], rx, ry)
+    assert e.max() <= TOL_F64
+    # Newton's third law: sum_i m_i a_i = 0 (the clamp max(R_i,R_j) is symmetric) — size-independent property
+    tot = np.abs(np.sum(ax.astype(np.float64))) + np.abs(np.sum(ay.astype(np.float64)))
+    assert tot <= 1e-5 * np.sum(np.hypot(ax, ay).astype(np.float64))
+
+
+def test_n1m_full_size_properties(nb, O):
+    """BASELINE metric size N = 2^20: sampled f64 check + momentum-conservation property."""
+    n = 1 << 20
+    b = O.init_disc(n, seed=12345)
+    ax, ay, _, _ = run_gpu(nb, b)
+    idx = np.linspace(0, n - 1, 256).astype(np.int32)
+    rx, ry = O.naive_accel_f64_subset(b, idx)
+    e = rel_err(ax[idx], ay[idx], rx, ry)
+    assert e.max() <= TOL_F64, e.max()
+    tot = np.abs(np.sum(ax.astype(np.float64))) + np.abs(np.sum(ay.astype(np.float64)))
+    assert tot <= 1e-5 * np.sum(np.hypot(ax, ay).astype(np.float64))
+
+
+def test_diagnostics_vs_oracle(nb, O):
+    b = O.init_disc(4096, seed=31)
+    b.posX *= 0.2; b.posY *= 0.2            # both potential branches populated
+    with nb.NBodySim(b.n, useBarnesHut=False) as sim:
+        sim.upload(*b.arrays())
+        d = sim.diagnostics()
+    ref = O.diagnostics(b)
+    got = np.array([d["Ekin"], d["Epot"], d["Px"], d["Py"], d["Lz"]])
+    assert np.isclose(got[0], ref[0], rtol=1e-9)
+    assert np.isclose(got[1], ref[1], rtol=2e-6)
+    scale = np.sum(b.m.astype(np.float64) * np.hypot(b.velX, b.velY))
+    assert abs(got[2] - ref[2]) <= 1e-9 * scale and abs(got[3] - ref[3]) <= 1e-9 * scale
+    assert np.isclose(got[4], ref[4], rtol=1e-9)
+
+
+def test_energy_and_momentum_drift_vs_cpu(nb, O):
+    """BASELINE config 2 (scaled to a CPU-affordable size): 100 forward-Euler steps on GPU and on the CPU
+    oracle from the same state.  Trajectories are chaotic, so compare conserved-quantity DRIFT:
+    total energy drift must agree within 2 % of |E0| at every checkpoint and total momentum must stay within
+    1e-4 of sum m|v| on both."""
+    n, dt = 4096, 0.01
+    b = O.init_disc(n, seed=77)
+    c = b.copy()
+    e_gpu, e_cpu, p_gpu = [], [], []
+    with nb.NBodySim(n, dt=dt, useBarnesHut=False) as sim:
+        sim.upload(*b.arrays())
+        d0 = sim.diagnostics()
+        e_gpu.append(d0["Ekin"] + d0["Epot"])
+        for _ in range(4):
+            sim.step(25)
+            d = sim.diagnostics()
+            e_gpu.append(d["Ekin"] + d["Epot"])
+            p_gpu.append(np.hypot(d["Px"] - d0["Px"], d["Py"] - d0["Py"]))
+    r0 = O.diagnostics(c)
+    e_cpu.append(r0[0] + r0[1])
+    for _ in range(4):
+        O.naive_steps(c, dt, 25)
+        r = O.diagnostics(c)
+        e_cpu.append(r[0] + r[1])
+    e_gpu, e_cpu = np.array(e_gpu), np.array(e_cpu)
+    assert np.isclose(e_gpu[0], e_cpu[0], rtol=1e-5)
+    drift_gpu = (e_gpu - e_gpu[0]) / abs(e_gpu[0])
+    drift_cpu = (e_cpu - e_cpu[0]) / abs(e_cpu[0])
+    assert np.all(np.abs(drift_gpu - drift_cpu) <= 0.02), (drift_gpu, drift_cpu)
+    scale = np.sum(b.m.astype(np.float64) * np.hypot(b.velX, b.velY))
+    assert max(p_gpu) <= 1e-4 * scale
+
+
+def test_two_shards_equal_one(nb, O):
+    """SURVEY.md §8e on one GPU: two contexts own the two i-shards; positions are exchanged through host
+    memory between steps (stand-in for the RCCL all-gather); result == the unsharded context, bit for bit."""
+    import ctypes as C
+    n = 5000
+    b = O.init_disc(n, seed=2)
+    _, _, ref, _ = run_gpu(nb, b, nsteps=3)
+    spans = [nb.shard_range(n, 2, r) for r in range(2)]
+    sims = [nb.NBodySim(n, dt=0.05, useBarnesHut=False, shard=s) for s in spans]
+    try:
+        for s in sims:
+            s.upload(*b.arrays())
+        cur = b.copy()
+        for _ in range(3):
+            outs = []
+            for s in sims:
+                s.step(1)
+                outs.append(s.download())
+            for (beg, cnt), o in zip(spans, outs):
+                for k in ("posX", "posY", "velX", "velY"):
+                    getattr(cur, k)[beg:beg + cnt] = o[k][beg:beg + cnt]
+            for s in sims:
+                s.upload(*cur.arrays())
+        for k in ("posX", "posY", "velX", "velY"):
+            assert np.abs(getattr(cur, k) - ref[k]).max() <= 2e-6 * max(1.0, np.abs(ref[k]).max()), k
+    finally:
+        for s in sims:
+            s.close()
+
+
+def test_profile_counters(nb, O):
+    b = O.init_disc(8192, seed=1)
+    with nb.NBodySim(b.n, useBarnesHut=False) as sim:
+        sim.upload(*b.arrays())
+        sim.profile(True)
+        sim.step(5)
+        ms, cnt = sim.profile_read(0)
+        ms_i, cnt_i = sim.profile_read(1)
+    assert cnt == 5 and cnt_i == 5 and ms > 0 and ms_i > 0
+
+
+def test_sharded_driver_torch_plumbing(nb, O):
+    """ShardedNaiveSim (what bench.py runs): torch stream hand-over, zero-copy torch views of the library's
+    posX/posY, and the in-place RCCL all-gather — exercised with a 1-rank `nccl` group on the one GPU here."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from nbody_amd.sharded import ShardedNaiveSim, exchange_slices
+    n = 4096
+    b = O.init_disc(n, seed=5)
+    _, _, ref, _ = run_gpu(nb, b, nsteps=2)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sim = ShardedNaiveSim(nb, n, 0, 1, device=0, dt=0.05, dist=dist)
+        sim.upload(*b.arrays())
+        sim.step(2)
+        exchange_slices(sim._pos, sim.spans, 0, dist)          # world=1: the collective itself, in place
+        sim.sync()
+        px = sim._pos[0].cpu().numpy()
+        st = sim.sim.download()
+        sim.close()
+    finally:
+        dist.destroy_process_group()
+    assert np.array_equal(px, ref["posX"])
+    for k in ref:
+        assert np.array_equal(st[k], ref[k]), k
