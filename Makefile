@@ -29,16 +29,16 @@ $(PKG)/bin/nbody_sim: $(PKG)/host/sim_main.cpp $(PKG)/host/config_reader.hpp $(P
 oracle:
 	$(MAKE) -C oracle all
 
-tools: tools/ubench tools/kbench
+tools: tools/ubench tools/kbench2
 
 tools/ubench: tools/ubench.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O2 $< -o $@
 
-tools/kbench: tools/kbench.hip $(KERNEL_HDRS)
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -I$(CSRC) $< -o $@
+tools/kbench2: tools/kbench2.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 $< -o $@
 
 clean:
-	rm -rf $(PKG)/lib $(PKG)/bin tools/ubench tools/kbench
+	rm -rf $(PKG)/lib $(PKG)/bin tools/ubench tools/kbench2
 	$(MAKE) -C oracle clean
 
 .PHONY: all lib host oracle tools clean

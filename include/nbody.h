@@ -55,8 +55,10 @@ typedef struct nbody_config {
        shard_count == 0 means the whole range.  Use nbody_shard_range() to compute it.            */
     int32_t shard_begin;
     int32_t shard_count;
-    int32_t force_variant;   /* 0 = auto (chosen at upload from the m/radius arrays),
-                                1 = uniform mass+radius, 2 = per-body mass+radius, 3 = exact-general */
+    int32_t force_variant;   /* 0 = auto (chosen at upload from the m/radius arrays); 1 = uniform mass and a
+                                uniform power-of-two radius >= 4 (pre-scaled coordinates, the reference's
+                                only case: R = 8), 2 = uniform mass+radius >= 4, 3 = per-body mass and
+                                radius >= 4, 4 = exact-general (any radius)                              */
     int32_t reserved[4];
 } nbody_config;
 
@@ -110,7 +112,7 @@ int nbody_profile_enable(nbody_ctx *ctx, int32_t on);
 int nbody_profile_read(nbody_ctx *ctx, int32_t which, double *total_ms, int64_t *launches);
 int nbody_profile_reset(nbody_ctx *ctx);
 
-/* Introspection for tests/bench: which force variant upload selected (1..3), grid geometry. */
+/* Introspection for tests/bench: which force variant upload selected (1..4), grid geometry. */
 int nbody_get_info(nbody_ctx *ctx, int32_t *force_variant, int32_t *j_slices, int32_t *blocks);
 
 /* Barnes-Hut tree read-back (parity hook for QuadTree::pool / lastPoolIndex, benchmark.cpp:73-74).

@@ -2,31 +2,50 @@
 //
 // Replaces benchmark.cpp:415-478 (pair loop) and benchmark.cpp:480-510
 // (integrator, row A2).  Not a translation: the reference broadcasts one source over 8 AVX lanes;
-// here every lane of a 64-wide wavefront owns K target bodies in registers, sources stream through
-// LDS as wave-uniform (broadcast) reads, and the pair formula is re-derived for the VALU:
+// here every lane of a 64-wide wavefront owns K target bodies in registers (as K/2 packed pairs),
+// sources stream through LDS as wave-uniform (broadcast) reads, and the pair formula is re-derived
+// for the gfx950 VALU, whose measured issue costs per wave64 instruction are (tools/ubench.hip):
+//     v_pk_{add,mul,fma}_f32  4 cycles for 2 results      v_{sub,mul,fma}_f32  2-2.5 cycles
+//     v_min/v_max/v_min3_f32  4 cycles                    v_rsq_f32 / v_rcp_f32  8 cycles
+//     any VALU op with an SGPR operand: 4 cycles          `clamp` output modifier: free
 //
 //   reference:  a_i += G m_j (r_j-r_i) * rcp(d) / (max(d, max(R_i,R_j))^2 + 0.001f^2)   [sqrt, rcp, div]
-//   here:       inv = rsq(d2);  a_i += (r_j-r_i) * m_j * inv * min(inv^2, c_i, c_j)      [one v_rsq_f32]
-//               with c = 1/(R^2 + 0.001f^2) precomputed per body at upload.
+//   here:       inv = rsq(d2);  a_i += (r_j-r_i) * m_j * inv * min(inv^2, c_i, c_j),  c = 1/(R^2+0.001f^2)
 //
-// 1/(max(d2,R2)+e) == min(1/(d2+e), 1/(R2+e)); replacing 1/(d2+e) by inv^2 = 1/d2 is exact to
-// < 1 ulp whenever the un-clamped branch is taken with d2 >= R2 >= 16 (e/d2 <= 6.3e-8), which the
-// host checks at upload (every reference configuration has R = 8, benchmark.cpp:338).  Inputs that
-// violate it run the EXACT variant (one extra v_rcp_f32).  d2 == 0 (self pair or coincident bodies,
-// masked by the reference at benchmark.cpp:468-472) contributes exactly 0 because dx = dy = 0 and
-// d2 carries a 1e-36 floor that keeps rsq finite — no compare/select in the loop.
+// 1/(max(d2,R2)+e) == min(1/(d2+e), 1/(R2+e)); replacing 1/(d2+e) by inv^2 = 1/d2 is exact to < 1 ulp
+// whenever the un-clamped branch is taken with d2 >= R2 >= 16 (e/d2 <= 6.3e-8), which the host checks at
+// upload (every reference configuration has R = 8, benchmark.cpp:338).  Inputs that violate it run the
+// EXACT variant (one extra v_rcp_f32).  d2 == 0 (self pair or coincident bodies, masked by the reference
+// at benchmark.cpp:468-472) contributes exactly 0 because dx = dy = 0 and d2 carries a 1e-36 floor that
+// keeps rsq finite — no compare/select in the loop.
+//
+// Fastest variant (kScaled) — what every reference configuration runs: uniform mass, uniform radius R
+// that is a power of two with R^2 + 1e-6 == R^2 in fp32 (R = 8: 64 + 1e-6 == 64.0f).  Coordinates are
+// pre-multiplied by 1/R (exact), so min(inv^2, 1/R^2) becomes clamp(inv'^2) to [0,1] — the free `clamp`
+// output modifier on the v_pk_mul_f32 that squares inv' — and the common factor m/R^2 is applied once at the end:
+//     per 2 interactions: 2 v_pk_add (dx,dy) + 2 v_pk_fma (d2) + 2 v_rsq + v_pk_mul clamp + v_pk_mul
+//                         + 2 v_pk_fma (accumulate)  = 8 packed + 2 transcendental = 48 issue cycles,
+// i.e. 24 cycles per interaction per wave64 against 20 at the "20 flop = 100 %" convention: the
+// instruction mix itself caps this kernel at 83 % of the 157.3 TFLOP/s headline (79 % at the 2.29 GHz the
+// chip holds under this load); measured 76 %.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace nbody {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 constexpr int kBlock = 256;          // 4 wavefronts
-constexpr int kTileJ = 1024;         // sources per LDS tile
 constexpr float kTiny = 1e-36f;      // d2 floor: rsq(1e-36) = 1e18, still finite after * m * c
 constexpr float kFarAway = 1.0e18f;  // padding source: d2 ~ 1e36 -> inv^3 underflows to 0
 constexpr float kSoft2 = 0.001f * 0.001f;  // benchmark.cpp:416,453
 
-enum ForceVariant : int { kUniform = 1, kPerBody = 2, kExact = 3 };
+enum ForceVariant : int { kScaled = 1, kUniform = 2, kPerBody = 3, kExact = 4 };
+
+// Sources per LDS tile: the big tile amortises the per-tile barrier at large N; the small one lets a
+// small N be cut into enough j-slices to fill 256 CUs (N = 10 000 -> 40 slices of 256 sources).
+constexpr int kTileSmall = 256;
+template <int V> struct Tile { static constexpr int kTileBig = (V == kScaled || V == kUniform) ? 2048 : 1024; };
 
 struct ForceArgs {
     const float* __restrict__ px;   // [n] source/target positions
@@ -38,110 +57,161 @@ struct ForceArgs {
     int n;                          // number of sources
     int i_begin, i_end;             // targets [i_begin, i_end)
     int i_stride;                   // row pitch of pax/pay (>= i_end - i_begin)
-    int j_per_slice;                // multiple of kTileJ
+    int j_per_slice;                // multiple of the variant's tile size
+    float pre_scale;                // kScaled: 1/R (power of two, exact); otherwise 1
     float uni_c;                    // kUniform: the common 1/(R^2+soft2)
-    float uni_m;                    // kUniform: the common mass (applied once at the end)
+    float out_scale;                // kScaled: m/R^2, kUniform: m, otherwise 1
 };
 
-template <int V>
-struct Src;                          // one source as staged in LDS
-template <>
-struct Src<kUniform> { float x, y; };
-template <>
-struct Src<kPerBody> { float x, y, m, c; };
-template <>
-struct Src<kExact> { float x, y, m, c; };
+template <int V> struct Src;         // one source as staged in LDS
+template <> struct Src<kScaled>  { float x, y; };
+template <> struct Src<kUniform> { float x, y; };
+template <> struct Src<kPerBody> { float x, y, m, c; };
+template <> struct Src<kExact>   { float x, y, m, c; };
 
+// One source against one packed pair of targets.  dx/dy are kept for the accumulate step.
 template <int V>
-__device__ __forceinline__ void interact(float xi, float yi, float ci, const Src<V>& s, float uni_c,
-                                         float& ax, float& ay)
+__device__ __forceinline__ f2 pair_weight(const f2 d2, const f2 ci, const Src<V>& s, const float uni_c)
 {
-    const float dx = s.x - xi;
-    const float dy = s.y - yi;
-    const float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, kTiny));
-    const float inv = __builtin_amdgcn_rsqf(d2);
-    float f;
-    if constexpr (V == kUniform) {
-        f = inv * __builtin_fminf(inv * inv, uni_c);
+    f2 inv;
+    inv.x = __builtin_amdgcn_rsqf(d2.x);
+    inv.y = __builtin_amdgcn_rsqf(d2.y);
+    if constexpr (V == kScaled) {
+        // min(inv'^2, 1) as the VOP3P `clamp` bit of the packed multiply that squares inv'.  hipcc does not
+        // fold a clamp into v_pk_mul_f32 by itself (it emits two half-rate v_max ... clamp), hence the asm.
+        // The leading s_nop is REQUIRED: a VALU read of a v_rsq_f32 result needs one wait state, and hipcc's
+        // hazard recogniser cannot see that this asm is such a read (without it, lanes come back stale).
+        f2 w;
+        asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %1 clamp" : "=v"(w) : "v"(inv));
+        return inv * w;
+    } else if constexpr (V == kUniform) {
+        f2 w = inv * inv;
+        w.x = __builtin_fminf(w.x, uni_c);
+        w.y = __builtin_fminf(w.y, uni_c);
+        return inv * w;
     } else if constexpr (V == kPerBody) {
-        f = (s.m * inv) * __builtin_fminf(__builtin_fminf(inv * inv, ci), s.c);
+        f2 w = inv * inv;
+        w.x = __builtin_fminf(__builtin_fminf(w.x, ci.x), s.c);
+        w.y = __builtin_fminf(__builtin_fminf(w.y, ci.y), s.c);
+        return (inv * w) * f2{s.m, s.m};
     } else {
-        const float den = __builtin_fmaxf(d2, __builtin_fmaxf(ci, s.c)) + kSoft2;
-        f = (s.m * inv) * __builtin_amdgcn_rcpf(den);
+        f2 den;
+        den.x = __builtin_fmaxf(__builtin_fmaxf(d2.x, ci.x), s.c);
+        den.y = __builtin_fmaxf(__builtin_fmaxf(d2.y, ci.y), s.c);
+        den = den + f2{kSoft2, kSoft2};
+        f2 r;
+        r.x = __builtin_amdgcn_rcpf(den.x);
+        r.y = __builtin_amdgcn_rcpf(den.y);
+        return (inv * r) * f2{s.m, s.m};
     }
-    ax = __builtin_fmaf(dx, f, ax);
-    ay = __builtin_fmaf(dy, f, ay);
 }
 
 // grid = (ceil(n_targets / (kBlock*K)), j_slices).  Block b handles targets
 // i_begin + b*kBlock*K + k*kBlock + tid (lane-contiguous => coalesced) against the sources of slice y.
-template <int V, int K>
-__global__ __launch_bounds__(kBlock) void force_naive_kernel(const ForceArgs a)
+// K targets per lane are held as K/2 packed pairs; JU sources are processed per inner iteration in
+// stage order (all dx/dy, all d2, all rsq, ...) so no dependent instructions sit back to back.
+template <int V, int K, int JU, int TJ>
+__global__ __launch_bounds__(kBlock, 4) void force_naive_kernel(const ForceArgs a)
 {
     using S = Src<V>;
-    __shared__ S tile[2][kTileJ];
+    constexpr int KP = K / 2, G = JU * KP;
+    static_assert(K % 2 == 0 && TJ % JU == 0 && TJ % kBlock == 0, "bad tiling");
+    __shared__ S tile[2][TJ];
 
     const int tid = threadIdx.x;
     const int i0 = a.i_begin + blockIdx.x * (kBlock * K) + tid;
     const int j_begin = blockIdx.y * a.j_per_slice;
     const int j_end = min(a.n, j_begin + a.j_per_slice);
 
-    float xi[K], yi[K], ci[K], ax[K], ay[K];
+    f2 X[KP], Y[KP], C[KP], AX[KP], AY[KP];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int i = min(i0 + k * kBlock, a.i_end - 1);   // clamp: out-of-range lanes compute, never store
-        xi[k] = a.px[i];
-        yi[k] = a.py[i];
-        ci[k] = (V == kUniform) ? 0.0f : a.c[i];
-        ax[k] = 0.0f;
-        ay[k] = 0.0f;
+    for (int k = 0; k < KP; ++k) {
+        // clamp: out-of-range lanes compute on a valid body and never store
+        const int ia = min(i0 + (2 * k) * kBlock, a.i_end - 1), ib = min(i0 + (2 * k + 1) * kBlock, a.i_end - 1);
+        X[k] = f2{a.px[ia] * a.pre_scale, a.px[ib] * a.pre_scale};
+        Y[k] = f2{a.py[ia] * a.pre_scale, a.py[ib] * a.pre_scale};
+        if constexpr (V == kPerBody || V == kExact) C[k] = f2{a.c[ia], a.c[ib]};
+        else C[k] = f2{0.0f, 0.0f};
+        AX[k] = f2{0.0f, 0.0f};
+        AY[k] = f2{0.0f, 0.0f};
     }
+    float tiny = kTiny;
+    asm volatile("" : "+v"(tiny));          // keep the floor in a VGPR (an SGPR operand halves the issue rate)
+    const f2 tiny2 = {tiny, tiny};
 
-    constexpr int kPer = kTileJ / kBlock;   // sources each thread stages per tile
-    S stage[kPer];
+    constexpr int kPer = TJ / kBlock;       // sources each thread stages per tile
+    // fetch() only ISSUES the (index-clamped, unconditional) global loads; every use of the loaded values —
+    // pre-scale, padding select, LDS store — is in commit(), after the pair loop, so the loads stay in flight
+    // under ~100k cycles of VALU work instead of being waited for one by one.
+    float rx[kPer], ry[kPer], rm[kPer], rc[kPer];
     auto fetch = [&](int j0) {
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
-            const int j = j0 + q * kBlock + tid;
-            const bool ok = j < j_end;
-            const int jc = ok ? j : 0;
-            stage[q].x = ok ? a.px[jc] : kFarAway;
-            stage[q].y = ok ? a.py[jc] : kFarAway;
-            if constexpr (V != kUniform) {
-                stage[q].m = ok ? a.m[jc] : 0.0f;
-                stage[q].c = a.c[jc];
-            }
+            const int jc = min(j0 + q * kBlock + tid, a.n - 1);
+            rx[q] = a.px[jc];
+            ry[q] = a.py[jc];
+            if constexpr (V == kPerBody || V == kExact) { rm[q] = a.m[jc]; rc[q] = a.c[jc]; }
         }
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, int j0) {
 #pragma unroll
-        for (int q = 0; q < kPer; ++q) tile[buf][q * kBlock + tid] = stage[q];
+        for (int q = 0; q < kPer; ++q) {
+            const bool ok = j0 + q * kBlock + tid < j_end;
+            S v;
+            v.x = ok ? rx[q] * a.pre_scale : kFarAway;
+            v.y = ok ? ry[q] * a.pre_scale : kFarAway;
+            if constexpr (V == kPerBody || V == kExact) { v.m = ok ? rm[q] : 0.0f; v.c = rc[q]; }
+            tile[buf][q * kBlock + tid] = v;
+        }
     };
 
     fetch(j_begin);
-    commit(0);
+    commit(0, j_begin);
     __syncthreads();
 
     int buf = 0;
-    for (int j0 = j_begin; j0 < j_end; j0 += kTileJ) {
-        const bool more = j0 + kTileJ < j_end;
-        if (more) fetch(j0 + kTileJ);          // global loads stay in flight under the pair loop
+    for (int j0 = j_begin; j0 < j_end; j0 += TJ) {
+        const bool more = j0 + TJ < j_end;
+        if (more) fetch(j0 + TJ);              // global loads stay in flight under the pair loop
 
-        float tx[K], ty[K];                    // per-tile partial sums: bounds fp32 accumulation error
+        f2 tx[KP], ty[KP];                     // per-tile partial sums: bounds fp32 accumulation error
 #pragma unroll
-        for (int k = 0; k < K; ++k) tx[k] = ty[k] = 0.0f;
+        for (int k = 0; k < KP; ++k) { tx[k] = f2{0.0f, 0.0f}; ty[k] = f2{0.0f, 0.0f}; }
 
         const S* __restrict__ t = tile[buf];
-#pragma unroll 8
-        for (int jj = 0; jj < kTileJ; ++jj) {
-            const S s = t[jj];                 // wave-uniform address: LDS broadcast read
+#pragma unroll 2
+        for (int jj = 0; jj < TJ; jj += JU) {
+            S s[JU];
+            f2 dx[G], dy[G], d2[G], f[G];
 #pragma unroll
-            for (int k = 0; k < K; ++k) interact<V>(xi[k], yi[k], ci[k], s, a.uni_c, tx[k], ty[k]);
+            for (int u = 0; u < JU; ++u) {
+                s[u] = t[jj + u];              // wave-uniform address: LDS broadcast read
+#pragma unroll
+                for (int k = 0; k < KP; ++k) {
+                    dx[u * KP + k] = f2{s[u].x, s[u].x} - X[k];
+                    dy[u * KP + k] = f2{s[u].y, s[u].y} - Y[k];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) d2[g] = __builtin_elementwise_fma(dy[g], dy[g], tiny2);
+#pragma unroll
+            for (int g = 0; g < G; ++g) d2[g] = __builtin_elementwise_fma(dx[g], dx[g], d2[g]);
+#pragma unroll
+            for (int u = 0; u < JU; ++u)
+#pragma unroll
+                for (int k = 0; k < KP; ++k) f[u * KP + k] = pair_weight<V>(d2[u * KP + k], C[k], s[u], a.uni_c);
+#pragma unroll
+            for (int u = 0; u < JU; ++u)
+#pragma unroll
+                for (int k = 0; k < KP; ++k) {
+                    tx[k] = __builtin_elementwise_fma(dx[u * KP + k], f[u * KP + k], tx[k]);
+                    ty[k] = __builtin_elementwise_fma(dy[u * KP + k], f[u * KP + k], ty[k]);
+                }
         }
 #pragma unroll
-        for (int k = 0; k < K; ++k) { ax[k] += tx[k]; ay[k] += ty[k]; }
+        for (int k = 0; k < KP; ++k) { AX[k] += tx[k]; AY[k] += ty[k]; }
 
-        if (more) commit(buf ^ 1);
+        if (more) commit(buf ^ 1, j0 + TJ);
         __syncthreads();
         buf ^= 1;
     }
@@ -149,13 +219,10 @@ __global__ __launch_bounds__(kBlock) void force_naive_kernel(const ForceArgs a)
     float* __restrict__ ox = a.pax + (size_t)blockIdx.y * a.i_stride;
     float* __restrict__ oy = a.pay + (size_t)blockIdx.y * a.i_stride;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int i = i0 + k * kBlock;
-        if (i < a.i_end) {
-            const float sc = (V == kUniform) ? a.uni_m : 1.0f;
-            ox[i - a.i_begin] = ax[k] * sc;
-            oy[i - a.i_begin] = ay[k] * sc;
-        }
+    for (int k = 0; k < KP; ++k) {
+        const int ia = i0 + (2 * k) * kBlock, ib = i0 + (2 * k + 1) * kBlock;
+        if (ia < a.i_end) { ox[ia - a.i_begin] = AX[k].x * a.out_scale; oy[ia - a.i_begin] = AY[k].x * a.out_scale; }
+        if (ib < a.i_end) { ox[ib - a.i_begin] = AX[k].y * a.out_scale; oy[ib - a.i_begin] = AY[k].y * a.out_scale; }
     }
 }
 
@@ -181,8 +248,21 @@ __global__ __launch_bounds__(256) void integrate_kernel(const IntegrateArgs a)
     const int i = a.i_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.i_end) return;
     const int r = i - a.i_begin;
+    // fixed summation order (slice 0, 1, 2, ...) => bit-reproducible; loads are issued 8 at a time so the
+    // reduction is not a chain of dependent HBM round trips
     float sx = 0.0f, sy = 0.0f;
-    for (int s = 0; s < a.slices; ++s) {
+    int s = 0;
+    for (; s + 8 <= a.slices; s += 8) {
+        float tx[8], ty[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            tx[u] = a.pax[(size_t)(s + u) * a.i_stride + r];
+            ty[u] = a.pay[(size_t)(s + u) * a.i_stride + r];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { sx += tx[u]; sy += ty[u]; }
+    }
+    for (; s < a.slices; ++s) {
         sx += a.pax[(size_t)s * a.i_stride + r];
         sy += a.pay[(size_t)s * a.i_stride + r];
     }

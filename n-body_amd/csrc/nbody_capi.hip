@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -66,8 +67,8 @@ struct nbody_ctx {
     int diag_blocks = 0;
     int i_begin = 0, i_end = 0;      // targets actually advanced (shard ∩ ref_compat limit)
     int i_stride = 0;
-    int variant = 0, slices = 1, k_per_lane = 2, j_per_slice = 0, blocks_x = 0;
-    float uni_m = 0, uni_c = 0;
+    int variant = 0, slices = 1, k_per_lane = 2, j_per_slice = 0, blocks_x = 0, tile = 0;
+    float uni_c = 0, pre_scale = 1, out_scale = 1;
     bool uploaded = false;
     Profiler prof;
 };
@@ -108,11 +109,21 @@ int profile_end(nbody_ctx* ctx, int cls, EventPair* ep)
     return NBODY_OK;
 }
 
-template <int V, int K>
-void launch_force(const ForceArgs& a, dim3 grid, hipStream_t s)
+template <int V>
+void launch_force_k(int K, int tile, const ForceArgs& a, dim3 grid, hipStream_t s)
 {
-    force_naive_kernel<V, K><<<grid, dim3(kBlock), 0, s>>>(a);
+    constexpr int JU = 4;
+    constexpr int kBig = Tile<V>::kTileBig;
+    if (tile == kTileSmall) {
+        if (K == 4) force_naive_kernel<V, 4, JU, kTileSmall><<<grid, dim3(kBlock), 0, s>>>(a);
+        else        force_naive_kernel<V, 2, JU, kTileSmall><<<grid, dim3(kBlock), 0, s>>>(a);
+    } else {
+        if (K == 4) force_naive_kernel<V, 4, JU, kBig><<<grid, dim3(kBlock), 0, s>>>(a);
+        else        force_naive_kernel<V, 2, JU, kBig><<<grid, dim3(kBlock), 0, s>>>(a);
+    }
 }
+
+int big_tile_of(int variant) { return (variant == kScaled || variant == kUniform) ? Tile<kScaled>::kTileBig : Tile<kPerBody>::kTileBig; }
 
 int enqueue_force(nbody_ctx* ctx)
 {
@@ -123,16 +134,17 @@ int enqueue_force(nbody_ctx* ctx)
     a.n = ctx->cfg.num_bodies;
     a.i_begin = ctx->i_begin; a.i_end = ctx->i_end; a.i_stride = ctx->i_stride;
     a.j_per_slice = ctx->j_per_slice;
-    a.uni_c = ctx->uni_c; a.uni_m = ctx->uni_m;
+    a.pre_scale = ctx->pre_scale; a.uni_c = ctx->uni_c; a.out_scale = ctx->out_scale;
     dim3 grid(ctx->blocks_x, ctx->slices);
     EventPair* ep;
     int rc = profile_begin(ctx, 0, &ep);
     if (rc) return rc;
     const int K = ctx->k_per_lane;
     switch (ctx->variant) {
-        case kUniform: (K == 1) ? launch_force<kUniform, 1>(a, grid, ctx->stream) : launch_force<kUniform, 2>(a, grid, ctx->stream); break;
-        case kPerBody: (K == 1) ? launch_force<kPerBody, 1>(a, grid, ctx->stream) : launch_force<kPerBody, 2>(a, grid, ctx->stream); break;
-        case kExact:   (K == 1) ? launch_force<kExact, 1>(a, grid, ctx->stream)   : launch_force<kExact, 2>(a, grid, ctx->stream); break;
+        case kScaled:  launch_force_k<kScaled>(K, ctx->tile, a, grid, ctx->stream); break;
+        case kUniform: launch_force_k<kUniform>(K, ctx->tile, a, grid, ctx->stream); break;
+        case kPerBody: launch_force_k<kPerBody>(K, ctx->tile, a, grid, ctx->stream); break;
+        case kExact:   launch_force_k<kExact>(K, ctx->tile, a, grid, ctx->stream); break;
         default: return fail(NBODY_ERR_INVALID, "no force variant selected");
     }
     HIP_TRY(hipGetLastError());
@@ -156,20 +168,38 @@ int enqueue_integrate(nbody_ctx* ctx, int advance)
     return profile_end(ctx, 1, ep);
 }
 
-// Geometry of the force launch: enough workgroups to fill 256 CUs several times over.
+// Geometry of the force launch: enough workgroups to fill 256 CUs several times over, so that the
+// dispatcher can even out the load (one workgroup = 4 waves; 256 CUs x 4 SIMDs want >= 2 waves each).
 void plan_force(nbody_ctx* ctx)
 {
     const int n = ctx->cfg.num_bodies;
     const int nt = ctx->i_end - ctx->i_begin;
-    ctx->k_per_lane = nt >= (1 << 17) ? 2 : 1;
-    ctx->blocks_x = (nt + kBlock * ctx->k_per_lane - 1) / (kBlock * ctx->k_per_lane);
+    const int big = big_tile_of(ctx->variant ? ctx->variant : (int)kScaled);
+    int k = nt >= (1 << 15) ? 4 : 2;
+    int want = 0;                                  // 0 = derive from the workgroup target
+    // developer tuning knobs (not part of the ABI): NBODY_FORCE_K = 2|4, NBODY_FORCE_SLICES = 1..64,
+    // NBODY_FORCE_TILE = small|big
+    if (const char* e = std::getenv("NBODY_FORCE_K")) {
+        const int v = std::atoi(e);
+        if (v == 2 || v == 4) k = v;
+    }
+    if (const char* e = std::getenv("NBODY_FORCE_SLICES")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= kMaxSlices) want = v;
+    }
+    ctx->k_per_lane = k;
+    ctx->blocks_x = (nt + kBlock * k - 1) / (kBlock * k);
     if (ctx->blocks_x < 1) ctx->blocks_x = 1;
-    const int max_slices_by_n = (n + kTileJ - 1) / kTileJ;
-    int want = (4096 + ctx->blocks_x - 1) / ctx->blocks_x;   // aim for >= 4096 workgroups
+    if (want == 0) want = (8192 + ctx->blocks_x - 1) / ctx->blocks_x;   // aim for >= 8192 workgroups (measured: tools/sweep.py)
     if (want > kMaxSlices) want = kMaxSlices;
+    // tile: the big one unless that leaves fewer slices than wanted
+    int tile = ((n + want - 1) / want >= big) ? big : kTileSmall;
+    if (const char* e = std::getenv("NBODY_FORCE_TILE")) tile = (e[0] == 's') ? kTileSmall : big;
+    const int max_slices_by_n = (n + tile - 1) / tile;
     if (want > max_slices_by_n) want = max_slices_by_n;
     if (want < 1) want = 1;
-    int jps = ((n + want - 1) / want + kTileJ - 1) / kTileJ * kTileJ;
+    const int jps = ((n + want - 1) / want + tile - 1) / tile * tile;
+    ctx->tile = tile;
     ctx->j_per_slice = jps;
     ctx->slices = (n + jps - 1) / jps;
 }
@@ -217,7 +247,7 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
     if (!(cfg->dt == cfg->dt)) return fail(NBODY_ERR_INVALID, "nbody_create: dt is NaN");
     if (cfg->shard_begin < 0 || cfg->shard_count < 0 || (int64_t)cfg->shard_begin + cfg->shard_count > n)
         return fail(NBODY_ERR_INVALID, "nbody_create: shard [%d,+%d) outside [0,%d)", cfg->shard_begin, cfg->shard_count, n);
-    if (cfg->force_variant < 0 || cfg->force_variant > 3)
+    if (cfg->force_variant < 0 || cfg->force_variant > 4)
         return fail(NBODY_ERR_INVALID, "nbody_create: force_variant=%d", cfg->force_variant);
     if (cfg->use_barnes_hut)
         return fail(NBODY_ERR_UNSUPPORTED, "nbody_create: Barnes-Hut path not built yet");
@@ -310,14 +340,23 @@ int nbody_upload(nbody_ctx* ctx, const float* m, const float* posX, const float*
     if (!finite) return fail(NBODY_ERR_INVALID, "nbody_upload: non-finite mass/radius/position");
     int variant = ctx->cfg.force_variant;
     const bool clamp_ok = rmin >= 4.0f;          // R^2 >= 16: inv^2 stands in for 1/(d2+1e-6) to < 1 ulp
-    if (variant == 0) variant = !clamp_ok ? kExact : (uni_m && uni_r ? kUniform : kPerBody);
+    const float r0 = radius[0];
+    int r_exp = 0;
+    // pre-scaling by 1/R is exact iff R is a power of two; clamp(inv'^2) == min(inv^2, 1/(R^2+soft2))*R^2
+    // iff R^2 + soft2 rounds to R^2 in fp32
+    const bool scalable = uni_m && uni_r && clamp_ok && std::frexp(r0, &r_exp) == 0.5f && (r0 * r0 + kSoft2 == r0 * r0);
+    if (variant == 0) variant = !clamp_ok ? kExact : (scalable ? kScaled : (uni_m && uni_r ? kUniform : kPerBody));
+    if (variant == kScaled && !scalable)
+        return fail(NBODY_ERR_INVALID, "nbody_upload: force_variant=scaled needs constant m and a constant power-of-two radius >= 4");
     if (variant == kUniform && !(uni_m && uni_r))
         return fail(NBODY_ERR_INVALID, "nbody_upload: force_variant=uniform but m/radius arrays are not constant");
-    if ((variant == kUniform || variant == kPerBody) && !clamp_ok)
+    if (variant != kExact && !clamp_ok)
         return fail(NBODY_ERR_INVALID, "nbody_upload: force_variant %d needs every radius >= 4 (min %g)", variant, rmin);
     ctx->variant = variant;
-    ctx->uni_m = m[0];
-    ctx->uni_c = 1.0f / (radius[0] * radius[0] + kSoft2);
+    ctx->uni_c = 1.0f / (r0 * r0 + kSoft2);
+    ctx->pre_scale = variant == kScaled ? 1.0f / r0 : 1.0f;
+    ctx->out_scale = variant == kScaled ? m[0] / (r0 * r0) : (variant == kUniform ? m[0] : 1.0f);
+    plan_force(ctx);
     std::vector<float> c((size_t)n);
     for (int i = 0; i < n; ++i)
         c[i] = variant == kExact ? radius[i] * radius[i] : 1.0f / (radius[i] * radius[i] + kSoft2);

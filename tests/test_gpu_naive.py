@@ -42,7 +42,7 @@ def test_accel_vs_oracle_and_reference(nb, O, name):
     assert np.all(ax[lim:] == 0) and np.all(ay[lim:] == 0)      # tail never a target (benchmark.cpp:423)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_all_force_variants_on_reference_data(nb, O, variant):
     _, b = load_golden(O, "naive_n10000")
     ax, ay, _, info = run_gpu(nb, b, force_variant=variant)
@@ -57,7 +57,35 @@ def test_per_body_mass_and_radius(nb, O):
     b.m[:] = rng.uniform(10.0, 3000.0, b.n).astype(np.float32)
     b.radius[:] = rng.uniform(4.0, 30.0, b.n).astype(np.float32)
     ax, ay, _, info = run_gpu(nb, b)
+    assert info["force_variant"] == 3
+    rx, ry = O.naive_accel_f64(b)
+    assert rel_err(ax, ay, rx, ry).max() <= TOL_F64
+
+
+def test_uniform_non_power_of_two_radius(nb, O):
+    """uniform m and R, but R = 10 cannot be pre-scaled exactly -> the min() variant (2).  Same for
+    R = 4: 16 + 1e-6 does not round to 16 in fp32, so the clamp constant would be off by an ulp."""
+    b = O.init_disc(4096, seed=98)
+    b.posX *= 0.2; b.posY *= 0.2
+    b.radius[:] = 4.0
+    _, _, _, info = run_gpu(nb, b)
     assert info["force_variant"] == 2
+    b.radius[:] = 10.0
+    ax, ay, _, info = run_gpu(nb, b)
+    assert info["force_variant"] == 2
+    rx, ry = O.naive_accel_f64(b)
+    assert rel_err(ax, ay, rx, ry).max() <= TOL_F64
+    with pytest.raises(nb.NBodyError):
+        run_gpu(nb, b, force_variant=1)
+
+
+@pytest.mark.parametrize("radius", [8.0, 16.0, 64.0])
+def test_other_power_of_two_radii_use_scaled_variant(nb, O, radius):
+    b = O.init_disc(4096, seed=97)
+    b.posX *= 0.3; b.posY *= 0.3
+    b.radius[:] = radius
+    ax, ay, _, info = run_gpu(nb, b)
+    assert info["force_variant"] == 1
     rx, ry = O.naive_accel_f64(b)
     assert rel_err(ax, ay, rx, ry).max() <= TOL_F64
 
@@ -70,11 +98,11 @@ def test_small_radii_select_exact_variant(nb, O):
     b.radius[:] = rng.uniform(0.001, 0.5, b.n).astype(np.float32)
     b.m[:] = rng.uniform(1.0, 10.0, b.n).astype(np.float32)
     ax, ay, _, info = run_gpu(nb, b)
-    assert info["force_variant"] == 3
+    assert info["force_variant"] == 4
     rx, ry = O.naive_accel_f64(b)
     assert rel_err(ax, ay, rx, ry).max() <= TOL_F64
     with pytest.raises(nb.NBodyError):
-        run_gpu(nb, b, force_variant=2)
+        run_gpu(nb, b, force_variant=3)
 
 
 def test_crowded_clamp_branch(nb, O):
