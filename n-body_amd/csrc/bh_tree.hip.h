@@ -1,0 +1,437 @@
+// bh_tree.hip.h — Barnes-Hut on gfx950: tree build, centre-of-mass pass, theta-criterion walk.
+//
+// Replaces QuadTree::build / insert_recursive (benchmark.cpp:77-173),
+// computeForce_vec (benchmark.cpp:228-277, A5) and computeForce_kernel (benchmark.cpp:176-225, A6).
+//
+// The reference inserts bodies one by one, recursively and serially.  Its result, however, is canonical:
+// a region quadtree over the FIXED box [-spread,spread]^2 (benchmark.cpp:169) in which a cell is split
+// (all four children allocated, benchmark.cpp:105-108) iff it holds >= 2 bodies, children ordered
+// TL,TR,BL,BR = (-x-y, +x-y, -x+y, +x+y), split lines at the float midpoint (tl+br)/2 (benchmark.cpp:98-99),
+// bodies outside the box dropped (benchmark.cpp:83-85).  That tree is rebuilt here without any insertion:
+//
+//   1. bh_keys_kernel      per body: descend 31 levels with the reference's own float comparisons and
+//                          midpoints -> 62-bit path key (2 bits per level); out-of-box -> invalid key
+//   2. hipcub radix sort   (key, body) pairs; invalid keys sort last
+//  2b. bh_ties_kernel + bh_merge_kernel   second instances of bodies on split lines (see below)
+//   3. bh_count_kernel     common-prefix length (in levels) of neighbouring keys: the cell of depth d that
+//                          STARTS at sorted body i is internal iff lcp(i-1,i) < d <= lcp(i,i+1), so body i
+//                          owns max(0, lcp(i,i+1) - lcp(i-1,i)) internal cells;  exclusive scan -> cell ids
+//   4. bh_nodes_kernel     one thread per internal cell c: binary-search the three quadrant boundaries of
+//                          its body range, emit its four children at node indices 1+4c .. 4+4c (leaf with
+//                          its body / empty leaf / internal child with childBase = 1 + 4*id(child))
+//   5. bh_com_kernel       bottom-up, one launch per depth: mass = ((0+m0)+m1)+m2)+m3,
+//                          com = sum(com_k*m_k)/mass in child order (benchmark.cpp:122-141)
+//
+// Everything is deterministic (no atomics decide any index) and nothing synchronises with the host.
+// Node order is Morton order, not the reference's insertion order; topology, boxes, body indices, masses
+// and centres of mass are identical to oracle_tree_build() (tests compare them by traversal).
+// Bodies EXACTLY on a split line: the reference's bounds are inclusive on all four sides
+// (benchmark.cpp:83-85), so such a body is inserted into BOTH children of an internal cell and its mass is
+// counted twice from there up (97 bodies in 10^6 — root mass 1.0001e9).  Reproduced:
+// after the first sort, bh_ties_kernel finds every body whose first x- (or y-) tie lies at a depth that is
+// internal in the tree (depth < its leaf depth, known from the neighbours' common prefixes) and emits a second
+// instance with the upper-child path; the few instances are sorted and merged into the key array before the
+// cells are counted.  Not reproduced (second order, ~1e-8 of bodies): ties that only become internal because
+// of another tie instance.  Coincident bodies stop splitting at depth 31 (the reference recurses until its
+// 32N pool is exhausted, benchmark.cpp:102).
+//
+// Walk: one group of 8 consecutive body indices per 8 lanes (8 groups per wave64), the reference's vote
+// ("accept iff leaf or all 8 lanes far", benchmark.cpp:264-266) taken with one wave ballot, DFS order equal
+// to the reference's explicit stack (children pushed 0..3, popped 3..0), so every lane accumulates the same
+// nodes in the same order as oracle_bh_accel().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nbody {
+
+constexpr int kBhLevels = 31;                       // path-key digits (2 bits each)
+constexpr uint64_t kBhInvalidKey = 1ull << 63;      // outside the root box
+constexpr int kBhBlock = 256;
+constexpr int kBhStackDepth = 34;
+
+struct BhCounters {          // device-resident scalars of one build/walk
+    int valid;               // M: bodies inside the root box
+    int internal;            // I: internal cells
+    int overflow;            // node pool (1) or tie-instance buffer (2) too small
+    int ghosts;              // G: second instances of bodies on split lines
+    unsigned long long visits, accepts;
+};
+
+// walk record of a node: A = {comX, comY, mass, width}, B = {childBase (-1: leaf), bodyIndex (-1: none)}
+struct BhTree {
+    float4* __restrict__ A;
+    int2* __restrict__ B;
+    float4* __restrict__ box;            // {tlX, tlY, brX, brY} (read-back / child boxes)
+    uint8_t* __restrict__ depth;         // per internal cell
+    int* __restrict__ self;              // per internal cell: its node index
+    int cap_internal;
+};
+
+__device__ __forceinline__ int bh_lcp_levels(uint64_t a, uint64_t b)
+{
+    const uint64_t x = a ^ b;
+    int l = x ? (__builtin_clzll(x) - 2) / 2 : kBhLevels;
+    return l > kBhLevels - 1 ? kBhLevels - 1 : l;          // internal cells live at depth <= 30
+}
+
+// 1. path keys ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBhBlock) void bh_keys_kernel(const float* __restrict__ px, const float* __restrict__ py,
+                                                           int n, float spread, uint64_t* __restrict__ keys,
+                                                           int* __restrict__ vals)
+{
+    const int i = blockIdx.x * kBhBlock + threadIdx.x;
+    if (i >= n) return;
+    const float x = px[i], y = py[i];
+    float tlx = -spread, tly = -spread, brx = spread, bry = spread;
+    uint64_t key;
+    if (x < tlx || x > brx || y < tly || y > bry) {         // benchmark.cpp:83-85
+        key = kBhInvalidKey | (uint64_t)(uint32_t)i;       // keep invalid keys distinct and ordered
+    } else {
+        key = 0;
+#pragma unroll 1
+        for (int l = 0; l < kBhLevels; ++l) {
+            const float mx = (tlx + brx) / 2.0f, my = (tly + bry) / 2.0f;    // benchmark.cpp:98-99
+            const int qx = x > mx, qy = y > my;            // on the line -> lower child
+            key = (key << 2) | (uint64_t)(qy * 2 + qx);    // TL, TR, BL, BR (benchmark.cpp:105-108)
+            tlx = qx ? mx : tlx; brx = qx ? brx : mx;
+            tly = qy ? my : tly; bry = qy ? bry : my;
+        }
+    }
+    keys[i] = key;
+    vals[i] = i;
+}
+
+// number of valid (in-box) bodies = first sorted index with the invalid bit set
+__global__ void bh_valid_kernel(const uint64_t* __restrict__ keys, int n, BhCounters* __restrict__ ctr)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] & kBhInvalidKey) hi = mid; else lo = mid + 1;
+    }
+    ctr->valid = lo;
+}
+
+__global__ void bh_reset_kernel(BhCounters* __restrict__ ctr)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ctr->valid = 0;
+    ctr->internal = 0;
+    ctr->overflow = 0;
+    ctr->ghosts = 0;
+    ctr->visits = 0;
+    ctr->accepts = 0;
+}
+
+// One descent with the reference's float arithmetic.  force_level/force_axis: take the UPPER child on that axis
+// at that level regardless of the comparison (the second instance of a body sitting exactly on the split line).
+// Returns the key; reports the first level at which x (resp. y) equals the midpoint, or kBhLevels.
+__device__ __forceinline__ uint64_t bh_descend(float x, float y, float spread, int fx_level, int fy_level, int* tie_x,
+                                               int* tie_y)
+{
+    float tlx = -spread, tly = -spread, brx = spread, bry = spread;
+    uint64_t key = 0;
+    int tx = kBhLevels, ty = kBhLevels;
+#pragma unroll 1
+    for (int l = 0; l < kBhLevels; ++l) {
+        const float mx = (tlx + brx) / 2.0f, my = (tly + bry) / 2.0f;    // benchmark.cpp:98-99
+        if (x == mx && tx == kBhLevels) tx = l;
+        if (y == my && ty == kBhLevels) ty = l;
+        const int qx = (x > mx) || l == fx_level, qy = (y > my) || l == fy_level;   // on the line -> lower child
+        key = (key << 2) | (uint64_t)(qy * 2 + qx);                      // TL, TR, BL, BR (benchmark.cpp:105-108)
+        tlx = qx ? mx : tlx; brx = qx ? brx : mx;
+        tly = qy ? my : tly; bry = qy ? bry : my;
+    }
+    if (tie_x) *tie_x = tx;
+    if (tie_y) *tie_y = ty;
+    return key;
+}
+
+// 2b. second instances.  Runs on the sorted primaries; leaf depth of body i = 1 + max(lcp with its neighbours).
+__global__ __launch_bounds__(kBhBlock) void bh_ties_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
+                                                           const float* __restrict__ px, const float* __restrict__ py,
+                                                           float spread, BhCounters* __restrict__ ctr,
+                                                           uint64_t* __restrict__ gkeys, int* __restrict__ gvals, int gcap)
+{
+    const int i = blockIdx.x * kBhBlock + threadIdx.x;
+    const int M = ctr->valid;
+    if (i >= M) return;
+    const uint64_t k = keys[i];
+    const int lp = i > 0 ? bh_lcp_levels(keys[i - 1], k) : -1;
+    const int ln = i + 1 < M ? bh_lcp_levels(k, keys[i + 1]) : -1;
+    const int leaf_depth = 1 + (lp > ln ? lp : ln);           // 0 when the body is alone in the tree
+    const int b = vals[i];
+    const float x = px[b], y = py[b];
+    int tx, ty;
+    (void)bh_descend(x, y, spread, -1, -1, &tx, &ty);
+    const bool ax_on = tx < leaf_depth, ay_on = ty < leaf_depth;   // the cell where the tie happens is internal
+    if (!ax_on && !ay_on) return;
+    uint64_t out[3];
+    int cnt = 0;
+    if (ax_on) out[cnt++] = bh_descend(x, y, spread, tx, -1, nullptr, nullptr);
+    if (ay_on) out[cnt++] = bh_descend(x, y, spread, -1, ty, nullptr, nullptr);
+    if (ax_on && ay_on) out[cnt++] = bh_descend(x, y, spread, tx, ty, nullptr, nullptr);
+    const int slot = atomicAdd(&ctr->ghosts, cnt);             // a few hundred per million bodies
+    for (int q = 0; q < cnt; ++q) {
+        if (slot + q < gcap) { gkeys[slot + q] = out[q]; gvals[slot + q] = b; }
+        else ctr->overflow = 2;
+    }
+}
+
+// pad the unused tail of the instance buffer with keys that sort after everything else
+__global__ __launch_bounds__(kBhBlock) void bh_ghost_pad_kernel(const BhCounters* __restrict__ ctr, uint64_t* __restrict__ gkeys,
+                                                                int* __restrict__ gvals, int gcap)
+{
+    const int g = blockIdx.x * kBhBlock + threadIdx.x;
+    if (g >= gcap) return;
+    const int G = ctr->ghosts < gcap ? ctr->ghosts : gcap;
+    if (g >= G) { gkeys[g] = ~0ull; gvals[g] = -1; }
+}
+
+// merge sorted primaries [n] and sorted second instances [gcap] into one sorted array [n + gcap]
+__global__ __launch_bounds__(kBhBlock) void bh_merge_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals, int n,
+                                                            const uint64_t* __restrict__ gkeys, const int* __restrict__ gvals,
+                                                            int gcap, uint64_t* __restrict__ okeys, int* __restrict__ ovals)
+{
+    const int t = blockIdx.x * kBhBlock + threadIdx.x;
+    if (t < n) {
+        const uint64_t k = keys[t];
+        int lo = 0, hi = gcap;                                 // second instances with a smaller key
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (gkeys[mid] < k) lo = mid + 1; else hi = mid; }
+        okeys[t + lo] = k;
+        ovals[t + lo] = vals[t];
+    } else if (t < n + gcap) {
+        const int g = t - n;
+        const uint64_t k = gkeys[g];
+        int lo = 0, hi = n;                                    // primaries with a key <= mine
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] <= k) lo = mid + 1; else hi = mid; }
+        okeys[g + lo] = k;
+        ovals[g + lo] = gvals[g];
+    }
+}
+
+// 3. internal cells owned by each sorted body --------------------------------------------------------------
+__global__ __launch_bounds__(kBhBlock) void bh_count_kernel(const uint64_t* __restrict__ keys, int n,
+                                                            const BhCounters* __restrict__ ctr, int* __restrict__ cnt)
+{
+    const int i = blockIdx.x * kBhBlock + threadIdx.x;
+    if (i >= n) return;
+    const int M = ctr->valid;
+    int c = 0;
+    if (i < M) {
+        const uint64_t k = keys[i];
+        const int lp = i > 0 ? bh_lcp_levels(keys[i - 1], k) : -1;
+        const int ln = i + 1 < M ? bh_lcp_levels(k, keys[i + 1]) : -1;
+        c = ln > lp ? ln - lp : 0;
+    }
+    cnt[i] = c;
+}
+
+__device__ __forceinline__ int bh_lower_bound(const uint64_t* __restrict__ keys, int lo, int hi, uint64_t v)
+{
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// 4. nodes ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
+                                                            const int* __restrict__ cnt, const int* __restrict__ base, int n,
+                                                            const float* __restrict__ m, const float* __restrict__ px,
+                                                            const float* __restrict__ py, float spread, BhTree t,
+                                                            BhCounters* __restrict__ ctr)
+{
+    const int c = blockIdx.x * kBhBlock + threadIdx.x;
+    const int M = ctr->valid;
+    const int I = M >= 2 ? base[M - 1] + cnt[M - 1] : 0;
+    if (c == 0) {
+        ctr->internal = I < t.cap_internal ? I : t.cap_internal;
+        if (I > t.cap_internal) ctr->overflow = 1;
+        if (M < 2) {                                           // degenerate trees: root is a leaf / empty
+            const int b = M == 1 ? vals[0] : -1;
+            t.A[0] = make_float4(b >= 0 ? px[b] : 0.0f, b >= 0 ? py[b] : 0.0f, b >= 0 ? m[b] : 0.0f, 2.0f * spread);
+            t.B[0] = make_int2(-1, b);
+            t.box[0] = make_float4(-spread, -spread, spread, spread);
+        }
+    }
+    if (c >= I || c >= t.cap_internal) return;
+
+    // owner body i of cell c: last i with base[i] <= c
+    int lo = 0, hi = M;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (base[mid] <= c) lo = mid + 1; else hi = mid;
+    }
+    const int i = lo - 1;
+    const uint64_t ki = keys[i];
+    const int lp = i > 0 ? bh_lcp_levels(keys[i - 1], ki) : -1;
+    const int d = lp + 1 + (c - base[i]);                      // depth of this cell, 0..30
+    const int shift = 2 * (kBhLevels - d);
+    const uint64_t prefix = d ? ki >> shift : 0;
+
+    // box of the cell: replay the reference's midpoint arithmetic along the prefix
+    float tlx = -spread, tly = -spread, brx = spread, bry = spread;
+    for (int l = 0; l < d; ++l) {
+        const int q = (int)((ki >> (2 * (kBhLevels - 1 - l))) & 3);
+        const float mx = (tlx + brx) / 2.0f, my = (tly + bry) / 2.0f;
+        if (q & 1) tlx = mx; else brx = mx;
+        if (q & 2) tly = my; else bry = my;
+    }
+    if (c == 0) {
+        t.box[0] = make_float4(tlx, tly, brx, bry);
+        t.A[0] = make_float4(0.0f, 0.0f, 0.0f, brx - tlx);
+        t.B[0] = make_int2(1, -1);
+        t.self[0] = 0;
+    }
+    t.depth[c] = (uint8_t)d;
+
+    // body range [i, e) of the cell and its quadrant boundaries
+    const int e = d ? bh_lower_bound(keys, i + 1, M, (prefix + 1) << shift) : M;
+    const int cshift = shift - 2;
+    int s[5];
+    s[0] = i;
+    s[4] = e;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) s[q] = bh_lower_bound(keys, s[q - 1], e, ((prefix << 2) | (uint64_t)q) << cshift);
+
+    const float mx = (tlx + brx) / 2.0f, my = (tly + bry) / 2.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int node = 1 + 4 * c + q;
+        const float ctlx = (q & 1) ? mx : tlx, cbrx = (q & 1) ? brx : mx;
+        const float ctly = (q & 2) ? my : tly, cbry = (q & 2) ? bry : my;
+        t.box[node] = make_float4(ctlx, ctly, cbrx, cbry);
+        const float width = cbrx - ctlx;                       // benchmark.cpp:251
+        const int cntq = s[q + 1] - s[q];
+        int child_base = -1, body = -1;
+        float cx = 0.0f, cy = 0.0f, cm = 0.0f;
+        if (cntq >= 2 && d + 1 < kBhLevels) {
+            const int sq = s[q];
+            const int lpq = sq > 0 ? bh_lcp_levels(keys[sq - 1], keys[sq]) : -1;
+            const int cc = base[sq] + d - lpq;                 // id of the internal child
+            if (cc < t.cap_internal) {
+                child_base = 1 + 4 * cc;
+                t.self[cc] = node;
+            } else {                                           // pool exhausted: keep one body (benchmark.cpp:102)
+                body = vals[sq];
+            }
+        } else if (cntq >= 1) {
+            body = vals[s[q]];                                  // leaf (at the depth cap: first body only)
+        }
+        if (body >= 0) { cx = px[body]; cy = py[body]; cm = m[body]; }   // benchmark.cpp:89-92
+        t.A[node] = make_float4(cx, cy, cm, width);
+        t.B[node] = make_int2(child_base, body);
+    }
+}
+
+// 5. centre of mass, one launch per depth (deepest first) ---------------------------------------------------
+__global__ __launch_bounds__(kBhBlock) void bh_com_kernel(BhTree t, const BhCounters* __restrict__ ctr, int d)
+{
+    const int c = blockIdx.x * kBhBlock + threadIdx.x;
+    if (c >= ctr->internal || t.depth[c] != d) return;
+    const int self = t.self[c];
+    float ms = 0.0f, sx = 0.0f, sy = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {          // benchmark.cpp:126-135 in child order; FMAs as the reference's build contracts them
+        const float4 a = t.A[1 + 4 * c + q];
+        ms = ms + a.z;
+        sx = __builtin_fmaf(a.x, a.z, sx);
+        sy = __builtin_fmaf(a.y, a.z, sy);
+    }
+    float4 r = t.A[self];
+    r.z = ms;
+    if (ms > 0.0f) { r.x = sx / ms; r.y = sy / ms; }            // benchmark.cpp:137-141 (IEEE division)
+    t.A[self] = r;
+}
+
+// Walk --------------------------------------------------------------------------------------------------------
+struct BhWalkArgs {
+    const float4* __restrict__ A;
+    const int2* __restrict__ B;
+    const float* __restrict__ px;
+    const float* __restrict__ py;
+    const float* __restrict__ radius;
+    float* __restrict__ ax;          // [i_stride] row 0 of the partial buffer, indexed i - i_begin
+    float* __restrict__ ay;
+    BhCounters* __restrict__ ctr;
+    int i_begin, i_end;              // targets; i_begin is a multiple of 8
+    float theta;
+};
+
+__global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
+{
+#pragma clang fp contract(off)   // every fma below is explicit: lanes reproduce oracle_bh_accel() bit for bit
+    __shared__ int stack[kBhStackDepth][kBhBlock];              // one private column per lane: no cross-lane traffic
+    __shared__ unsigned long long red[2][kBhBlock / 64];
+    const int tid = threadIdx.x;
+    const int i = w.i_begin + blockIdx.x * kBhBlock + tid;
+    const bool live = i < w.i_end;
+    const int ic = live ? i : w.i_end - 1;
+    const float xi = w.px[ic], yi = w.py[ic], ri = w.radius[ic];
+    const int grp_shift = (tid & 63) & ~7;                      // first lane of this group inside the wave
+    const float eps = 1e-6f, soft2 = 0.001f * 0.001f;
+    float ax = 0.0f, ay = 0.0f;
+    unsigned visits = 0, accepts = 0;
+
+    // is any lane of my group a real target?
+    const unsigned long long live_mask = __ballot(live);
+    bool active = ((live_mask >> grp_shift) & 0xFFull) != 0;
+    int node = 0, sp = 0;
+    while (__any(active)) {
+        if (active) {
+            const float4 a = w.A[node];
+            const int2 b = w.B[node];
+            ++visits;
+            bool open = false;
+            if (a.z != 0.0f) {                                  // benchmark.cpp:248
+                const float dx = a.x - xi, dy = a.y - yi;       // :254-255
+                const float d = __builtin_sqrtf(__builtin_fmaf(dx, dx, dy * dy));   // :256-257
+                const bool far = (a.w / (d + eps)) < w.theta;                       // :259-262
+                const unsigned long long fm = __ballot(far || !live);
+                const bool all_far = ((fm >> grp_shift) & 0xFFull) == 0xFFull;
+                if (b.x < 0 || all_far) {                       // :266 leaf or every lane far
+                    ++accepts;
+                    // computeForce_kernel, benchmark.cpp:188-225
+                    const float sd = __builtin_fmaxf(d, ri);    // clamp radius is the TARGET's only (:201-202)
+                    const float f = a.z / __builtin_fmaf(sd, sd, soft2);   // :203-209
+                    const float inv = 1.0f / (d + eps);         // :212-213
+                    const bool self = b.y == i;                 // :197-198
+                    ax = ax + (self ? 0.0f : (dx * inv) * f);
+                    ay = ay + (self ? 0.0f : (dy * inv) * f);
+                } else {
+                    open = true;
+                }
+            }
+            const bool more_siblings = node != 0 && ((node - 1) & 3) != 0;
+            if (open) {
+                if (more_siblings) stack[sp++][tid] = node - 1;
+                node = b.x + 3;                                 // children pushed 0..3, popped 3..0 (:272-274, :244)
+            } else if (more_siblings) {
+                node = node - 1;
+            } else if (sp > 0) {
+                node = stack[--sp][tid];
+            } else {
+                active = false;
+            }
+        }
+    }
+    if (live) { w.ax[i - w.i_begin] = ax; w.ay[i - w.i_begin] = ay; }
+
+    // counters: one representative lane per group
+    unsigned long long v = (tid & 7) == 0 ? visits : 0, acc = (tid & 7) == 0 ? accepts : 0;
+    for (int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); acc += __shfl_down(acc, off, 64); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = v; red[1][tid >> 6] = acc; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long sv = 0, sa = 0;
+        for (int k = 0; k < kBhBlock / 64; ++k) { sv += red[0][k]; sa += red[1][k]; }
+        atomicAdd(&w.ctr->visits, sv);
+        atomicAdd(&w.ctr->accepts, sa);
+    }
+}
+
+}  // namespace nbody

@@ -6,6 +6,9 @@
 #include "../../include/nbody.h"
 #include "force_naive.hip.h"
 #include "diagnostics.hip.h"
+#include "bh_tree.hip.h"
+
+#include <hipcub/hipcub.hpp>
 
 #include <cmath>
 #include <cstdarg>
@@ -71,6 +74,20 @@ struct nbody_ctx {
     float uni_c = 0, pre_scale = 1, out_scale = 1;
     bool uploaded = false;
     Profiler prof;
+    // Barnes-Hut state (allocated only when cfg.use_barnes_hut)
+    struct Bh {
+        uint64_t *keys = nullptr, *keys_sorted = nullptr, *gkeys = nullptr, *gkeys_sorted = nullptr, *keys_merged = nullptr;
+        int *vals = nullptr, *vals_sorted = nullptr, *gvals = nullptr, *gvals_sorted = nullptr, *vals_merged = nullptr;
+        int *cnt = nullptr, *base = nullptr;
+        int gcap = 0;                    // capacity for second instances of bodies on split lines
+        void* gsort_tmp = nullptr;
+        size_t gsort_bytes = 0;
+        BhTree tree{};
+        BhCounters* ctr = nullptr;
+        void *sort_tmp = nullptr, *scan_tmp = nullptr;
+        size_t sort_bytes = 0, scan_bytes = 0;
+        int64_t node_cap = 0;
+    } bh;
 };
 
 namespace {
@@ -157,7 +174,8 @@ int enqueue_integrate(nbody_ctx* ctx, int advance)
     IntegrateArgs a{};
     a.px = ctx->px; a.py = ctx->py; a.vx = ctx->vx; a.vy = ctx->vy;
     a.pax = ctx->pax; a.pay = ctx->pay; a.ax = ctx->ax; a.ay = ctx->ay;
-    a.i_begin = ctx->i_begin; a.i_end = ctx->i_end; a.i_stride = ctx->i_stride; a.slices = ctx->slices;
+    a.i_begin = ctx->i_begin; a.i_end = ctx->i_end; a.i_stride = ctx->i_stride;
+    a.slices = ctx->cfg.use_barnes_hut ? 1 : ctx->slices;
     a.dt = ctx->cfg.dt; a.advance = advance;
     const int nt = ctx->i_end - ctx->i_begin;
     EventPair* ep;
@@ -166,6 +184,60 @@ int enqueue_integrate(nbody_ctx* ctx, int advance)
     integrate_kernel<<<dim3((nt + 255) / 256), dim3(256), 0, ctx->stream>>>(a);
     HIP_TRY(hipGetLastError());
     return profile_end(ctx, 1, ep);
+}
+
+
+// Barnes-Hut step = build (keys -> sort -> cells -> nodes -> centre of mass) + walk, benchmark.cpp:354-403.
+int enqueue_bh_build(nbody_ctx* ctx)
+{
+    auto& b = ctx->bh;
+    const int n = ctx->cfg.num_bodies;
+    const dim3 blk(kBhBlock), grid_n((n + kBhBlock - 1) / kBhBlock);
+    hipStream_t s = ctx->stream;
+    EventPair* ep;
+    int rc = profile_begin(ctx, 2, &ep);
+    if (rc) return rc;
+    const int nm = n + b.gcap;                                 // instances after the merge (tail = padding)
+    const dim3 grid_g((b.gcap + kBhBlock - 1) / kBhBlock), grid_m((nm + kBhBlock - 1) / kBhBlock);
+    bh_reset_kernel<<<1, 64, 0, s>>>(b.ctr);
+    bh_keys_kernel<<<grid_n, blk, 0, s>>>(ctx->px, ctx->py, n, ctx->cfg.spread, b.keys, b.vals);
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, b.keys, b.keys_sorted, b.vals, b.vals_sorted, n,
+                                               0, 64, s));
+    bh_valid_kernel<<<1, 64, 0, s>>>(b.keys_sorted, n, b.ctr);
+    // bodies exactly on a split line get a second instance (inclusive bounds, benchmark.cpp:83-85)
+    bh_ties_kernel<<<grid_n, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, ctx->cfg.spread, b.ctr, b.gkeys,
+                                          b.gvals, b.gcap);
+    bh_ghost_pad_kernel<<<grid_g, blk, 0, s>>>(b.ctr, b.gkeys, b.gvals, b.gcap);
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.gsort_tmp, b.gsort_bytes, b.gkeys, b.gkeys_sorted, b.gvals, b.gvals_sorted,
+                                               b.gcap, 0, 64, s));
+    bh_merge_kernel<<<grid_m, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, n, b.gkeys_sorted, b.gvals_sorted, b.gcap,
+                                           b.keys_merged, b.vals_merged);
+    bh_valid_kernel<<<1, 64, 0, s>>>(b.keys_merged, nm, b.ctr);
+    bh_count_kernel<<<grid_m, blk, 0, s>>>(b.keys_merged, nm, b.ctr, b.cnt);
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b.scan_tmp, b.scan_bytes, b.cnt, b.base, nm, s));
+    const dim3 grid_c((b.tree.cap_internal + kBhBlock - 1) / kBhBlock);
+    bh_nodes_kernel<<<grid_c, blk, 0, s>>>(b.keys_merged, b.vals_merged, b.cnt, b.base, nm, ctx->m, ctx->px, ctx->py,
+                                           ctx->cfg.spread, b.tree, b.ctr);
+    for (int d = kBhLevels - 1; d >= 0; --d) bh_com_kernel<<<grid_c, blk, 0, s>>>(b.tree, b.ctr, d);
+    HIP_TRY(hipGetLastError());
+    return profile_end(ctx, 2, ep);
+}
+
+int enqueue_bh_walk(nbody_ctx* ctx)
+{
+    if (ctx->i_end <= ctx->i_begin) return NBODY_OK;
+    BhWalkArgs w{};
+    w.A = ctx->bh.tree.A; w.B = ctx->bh.tree.B;
+    w.px = ctx->px; w.py = ctx->py; w.radius = ctx->radius;
+    w.ax = ctx->pax; w.ay = ctx->pay; w.ctr = ctx->bh.ctr;
+    w.i_begin = ctx->i_begin; w.i_end = ctx->i_end; w.theta = ctx->cfg.theta;
+    const int nt = ctx->i_end - ctx->i_begin;
+    EventPair* ep;
+    int rc = profile_begin(ctx, 0, &ep);
+    if (rc) return rc;
+    bh_walk_kernel<<<dim3((nt + kBhBlock - 1) / kBhBlock), dim3(kBhBlock), 0, ctx->stream>>>(w);
+    HIP_TRY(hipGetLastError());
+    return profile_end(ctx, 0, ep);
 }
 
 // Geometry of the force launch: enough workgroups to fill 256 CUs several times over, so that the
@@ -249,8 +321,10 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
         return fail(NBODY_ERR_INVALID, "nbody_create: shard [%d,+%d) outside [0,%d)", cfg->shard_begin, cfg->shard_count, n);
     if (cfg->force_variant < 0 || cfg->force_variant > 4)
         return fail(NBODY_ERR_INVALID, "nbody_create: force_variant=%d", cfg->force_variant);
-    if (cfg->use_barnes_hut)
-        return fail(NBODY_ERR_UNSUPPORTED, "nbody_create: Barnes-Hut path not built yet");
+    if (cfg->use_barnes_hut && !(cfg->spread > 0.0f))
+        return fail(NBODY_ERR_INVALID, "nbody_create: Barnes-Hut needs spread > 0 (root box), got %g", cfg->spread);
+    if (cfg->use_barnes_hut && cfg->shard_begin % 8 != 0)
+        return fail(NBODY_ERR_INVALID, "nbody_create: Barnes-Hut shards must start on a multiple of 8 (groups of 8 bodies)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(NBODY_ERR_NO_DEVICE, "nbody_create: no HIP device visible (there is no CPU fallback)");
@@ -292,6 +366,40 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
     HIP_TRY_C(hipMalloc((void**)&ctx->diag_partials, sizeof(double) * 5 * (size_t)ctx->diag_blocks));
     HIP_TRY_C(hipMemset(ctx->ax, 0, nb));
     HIP_TRY_C(hipMemset(ctx->ay, 0, nb));
+    if (cfg->use_barnes_hut) {
+        auto& b = ctx->bh;
+        // the reference reserves 32 N nodes (benchmark.cpp:148) and uses ~2.9 N;
+        // here: 2 N + 64 internal cells => 8 N + 257 nodes of 40 B
+        b.tree.cap_internal = 2 * n + 64;
+        b.node_cap = 1 + 4 * (int64_t)b.tree.cap_internal;
+        HIP_TRY_C(hipMalloc((void**)&b.keys, sizeof(uint64_t) * (size_t)n));
+        HIP_TRY_C(hipMalloc((void**)&b.keys_sorted, sizeof(uint64_t) * (size_t)n));
+        HIP_TRY_C(hipMalloc((void**)&b.vals, sizeof(int) * (size_t)n));
+        HIP_TRY_C(hipMalloc((void**)&b.vals_sorted, sizeof(int) * (size_t)n));
+        b.gcap = n / 256 > 4096 ? n / 256 : 4096;
+        const size_t nm = (size_t)n + (size_t)b.gcap;
+        HIP_TRY_C(hipMalloc((void**)&b.gkeys, sizeof(uint64_t) * (size_t)b.gcap));
+        HIP_TRY_C(hipMalloc((void**)&b.gkeys_sorted, sizeof(uint64_t) * (size_t)b.gcap));
+        HIP_TRY_C(hipMalloc((void**)&b.gvals, sizeof(int) * (size_t)b.gcap));
+        HIP_TRY_C(hipMalloc((void**)&b.gvals_sorted, sizeof(int) * (size_t)b.gcap));
+        HIP_TRY_C(hipMalloc((void**)&b.keys_merged, sizeof(uint64_t) * nm));
+        HIP_TRY_C(hipMalloc((void**)&b.vals_merged, sizeof(int) * nm));
+        HIP_TRY_C(hipMalloc((void**)&b.cnt, sizeof(int) * nm));
+        HIP_TRY_C(hipMalloc((void**)&b.base, sizeof(int) * nm));
+        HIP_TRY_C(hipMalloc((void**)&b.tree.A, sizeof(float4) * (size_t)b.node_cap));
+        HIP_TRY_C(hipMalloc((void**)&b.tree.B, sizeof(int2) * (size_t)b.node_cap));
+        HIP_TRY_C(hipMalloc((void**)&b.tree.box, sizeof(float4) * (size_t)b.node_cap));
+        HIP_TRY_C(hipMalloc((void**)&b.tree.depth, (size_t)b.tree.cap_internal));
+        HIP_TRY_C(hipMalloc((void**)&b.tree.self, sizeof(int) * (size_t)b.tree.cap_internal));
+        HIP_TRY_C(hipMalloc((void**)&b.ctr, sizeof(BhCounters)));
+        HIP_TRY_C(hipMemset(b.ctr, 0, sizeof(BhCounters)));
+        HIP_TRY_C(hipcub::DeviceRadixSort::SortPairs(nullptr, b.sort_bytes, b.keys, b.keys_sorted, b.vals, b.vals_sorted, n, 0, 64, ctx->stream));
+        HIP_TRY_C(hipcub::DeviceRadixSort::SortPairs(nullptr, b.gsort_bytes, b.gkeys, b.gkeys_sorted, b.gvals, b.gvals_sorted, b.gcap, 0, 64, ctx->stream));
+        HIP_TRY_C(hipcub::DeviceScan::ExclusiveSum(nullptr, b.scan_bytes, b.cnt, b.base, (int)nm, ctx->stream));
+        HIP_TRY_C(hipMalloc(&b.gsort_tmp, b.gsort_bytes ? b.gsort_bytes : 16));
+        HIP_TRY_C(hipMalloc(&b.sort_tmp, b.sort_bytes ? b.sort_bytes : 16));
+        HIP_TRY_C(hipMalloc(&b.scan_tmp, b.scan_bytes ? b.scan_bytes : 16));
+    }
 #undef HIP_TRY_C
     *out = ctx;
     return NBODY_OK;
@@ -306,6 +414,14 @@ void nbody_destroy(nbody_ctx* ctx)
     for (float* p : arrs)
         if (p) (void)hipFree(p);
     if (ctx->diag_partials) (void)hipFree(ctx->diag_partials);
+    {
+        auto& b = ctx->bh;
+        void* ptrs[] = {b.keys, b.keys_sorted, b.vals, b.vals_sorted, b.cnt, b.base, b.tree.A, b.tree.B, b.tree.box,
+                        b.tree.depth, b.tree.self, b.ctr, b.sort_tmp, b.scan_tmp, b.gkeys, b.gkeys_sorted, b.gvals,
+                        b.gvals_sorted, b.keys_merged, b.vals_merged, b.gsort_tmp};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    }
     for (auto& pool : ctx->prof.pool)
         for (auto& ep : pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -383,9 +499,17 @@ int nbody_step(nbody_ctx* ctx, int32_t nsteps)
     if (nsteps < 0) return fail(NBODY_ERR_INVALID, "nbody_step: nsteps=%d", nsteps);
     HIP_TRY(hipSetDevice(ctx->device));
     for (int s = 0; s < nsteps; ++s) {
-        int rc = enqueue_force(ctx);
+        int rc;
+        if (ctx->cfg.use_barnes_hut) {
+            rc = enqueue_bh_build(ctx);                      // benchmark.cpp:357
+            if (rc) return rc;
+            if (!ctx->cfg.use_parallel) continue;            // benchmark.cpp:359: tree built, nothing else happens
+            rc = enqueue_bh_walk(ctx);                       // :365-380
+        } else {
+            rc = enqueue_force(ctx);                         // :407-478
+        }
         if (rc) return rc;
-        rc = enqueue_integrate(ctx, 1);
+        rc = enqueue_integrate(ctx, 1);                      // :382-401 / :480-510
         if (rc) return rc;
     }
     return NBODY_OK;
@@ -396,7 +520,14 @@ int nbody_compute_accel(nbody_ctx* ctx)
     if (!ctx) return fail(NBODY_ERR_INVALID, "nbody_compute_accel: null context");
     if (!ctx->uploaded) return fail(NBODY_ERR_INVALID, "nbody_compute_accel: nbody_upload has not been called");
     HIP_TRY(hipSetDevice(ctx->device));
-    int rc = enqueue_force(ctx);
+    int rc;
+    if (ctx->cfg.use_barnes_hut) {
+        rc = enqueue_bh_build(ctx);
+        if (rc) return rc;
+        rc = enqueue_bh_walk(ctx);
+    } else {
+        rc = enqueue_force(ctx);
+    }
     if (rc) return rc;
     return enqueue_integrate(ctx, 0);
 }
@@ -406,6 +537,16 @@ int nbody_sync(nbody_ctx* ctx)
     if (!ctx) return fail(NBODY_ERR_INVALID, "nbody_sync: null context");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->cfg.use_barnes_hut) {
+        BhCounters h{};
+        HIP_TRY(hipMemcpy(&h, ctx->bh.ctr, sizeof(h), hipMemcpyDeviceToHost));
+        if (h.overflow == 1)
+            return fail(NBODY_ERR_INVALID, "Barnes-Hut node pool exhausted (%d internal cells); bodies were dropped from the tree "
+                                           "as the reference does at benchmark.cpp:102", ctx->bh.tree.cap_internal);
+        if (h.overflow == 2)
+            return fail(NBODY_ERR_INVALID, "Barnes-Hut: more than %d bodies sit exactly on split lines; the surplus was inserted once",
+                        ctx->bh.gcap);
+    }
     return NBODY_OK;
 }
 
@@ -505,14 +646,47 @@ int nbody_get_info(nbody_ctx* ctx, int32_t* force_variant, int32_t* j_slices, in
 
 int64_t nbody_bh_tree_nodes(nbody_ctx* ctx, void* out, int64_t cap)
 {
-    (void)ctx; (void)out; (void)cap;
-    return fail(NBODY_ERR_UNSUPPORTED, "nbody_bh_tree_nodes: Barnes-Hut path not built yet");
+    if (!ctx) return fail(NBODY_ERR_INVALID, "nbody_bh_tree_nodes: null context");
+    if (!ctx->cfg.use_barnes_hut) return fail(NBODY_ERR_INVALID, "nbody_bh_tree_nodes: context is not in Barnes-Hut mode");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    BhCounters h{};
+    HIP_TRY(hipMemcpy(&h, ctx->bh.ctr, sizeof(h), hipMemcpyDeviceToHost));
+    const int64_t nodes = 1 + 4 * (int64_t)h.internal;
+    if (!out) return nodes;
+    const int64_t k = nodes < cap ? nodes : cap;
+    if (k <= 0) return nodes;
+    std::vector<float4> A((size_t)k), box((size_t)k);
+    std::vector<int2> B((size_t)k);
+    HIP_TRY(hipMemcpy(A.data(), ctx->bh.tree.A, sizeof(float4) * (size_t)k, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(B.data(), ctx->bh.tree.B, sizeof(int2) * (size_t)k, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(box.data(), ctx->bh.tree.box, sizeof(float4) * (size_t)k, hipMemcpyDeviceToHost));
+    struct QuadNodeRecord {   // layout of the reference's QuadNode, benchmark.cpp:52-60
+        float mass, comX, comY, tlX, tlY, brX, brY;
+        int32_t bodyIndex, children[4];
+    };
+    static_assert(sizeof(QuadNodeRecord) == 48, "QuadNode is 48 bytes");
+    QuadNodeRecord* o = (QuadNodeRecord*)out;
+    for (int64_t i = 0; i < k; ++i) {
+        o[i].mass = A[i].z; o[i].comX = A[i].x; o[i].comY = A[i].y;
+        o[i].tlX = box[i].x; o[i].tlY = box[i].y; o[i].brX = box[i].z; o[i].brY = box[i].w;
+        o[i].bodyIndex = B[i].y;
+        for (int q = 0; q < 4; ++q) o[i].children[q] = B[i].x >= 0 ? B[i].x + q : -1;
+    }
+    return nodes;
 }
 
 int nbody_bh_counters(nbody_ctx* ctx, int64_t out[2])
 {
-    (void)ctx; (void)out;
-    return fail(NBODY_ERR_UNSUPPORTED, "nbody_bh_counters: Barnes-Hut path not built yet");
+    if (!ctx || !out) return fail(NBODY_ERR_INVALID, "nbody_bh_counters: null argument");
+    if (!ctx->cfg.use_barnes_hut) return fail(NBODY_ERR_INVALID, "nbody_bh_counters: context is not in Barnes-Hut mode");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    BhCounters h{};
+    HIP_TRY(hipMemcpy(&h, ctx->bh.ctr, sizeof(h), hipMemcpyDeviceToHost));
+    out[0] = (int64_t)h.visits;
+    out[1] = (int64_t)h.accepts;
+    return NBODY_OK;
 }
 
 const char* nbody_last_error(void) { return g_err; }

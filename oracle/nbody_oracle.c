@@ -204,10 +204,12 @@ void oracle_euler_f32(int n, float *px, float *py, float *vx, float *vy,
 {
     int lim = target_limit(n, ref_compat);                      /* :486 */
     for (int i = 0; i < lim; ++i) {
-        px[i] = px[i] + vx[i] * dt;                             /* :498-499 */
-        py[i] = py[i] + vy[i] * dt;
-        vx[i] = vx[i] + ax[i] * dt;                             /* :502-503 */
-        vy[i] = vy[i] + ay[i] * dt;
+        /* add(x, mul(v, dt)) in the source; the reference's -O3 -ffast-math build contracts it into one FMA
+         * (checked against the golden step-1 state: bit-exact with fmaf, 1-ulp misses without) */
+        px[i] = fmaf(vx[i], dt, px[i]);                         /* :498-499 */
+        py[i] = fmaf(vy[i], dt, py[i]);
+        vx[i] = fmaf(ax[i], dt, vx[i]);                         /* :502-503 */
+        vy[i] = fmaf(ay[i], dt, vy[i]);
     }
 }
 
@@ -313,7 +315,9 @@ static void tree_insert(oracle_tree *t, int ni, int b, const float *m, const flo
     for (int k = 0; k < 4; ++k) {
         if (nd->children[k] != -1) {
             const oracle_node *c = &t->pool[nd->children[k]];
-            ms += c->mass; sx += c->comX * c->mass; sy += c->comY * c->mass;
+            /* the reference's -O3 -ffast-math build contracts these into FMAs (checked: with fmaf the
+             * root COM of the golden N=1024 tree is reproduced to the last bit, without it it is not) */
+            ms += c->mass; sx = fmaf(c->comX, c->mass, sx); sy = fmaf(c->comY, c->mass, sy);
         }
     }
     nd->mass = ms;
@@ -388,7 +392,7 @@ static void bh_group(const oracle_tree *t, int start, int lanes, const float *px
         int all_far = 1;
         for (int k = 0; k < lanes; ++k) {
             float dx = nd->comX - px[start + k], dy = nd->comY - py[start + k];
-            float d = sqrtf(dx * dx + dy * dy);                               /* :256-257 */
+            float d = sqrtf(fmaf(dx, dx, dy * dy));                           /* :256-257 (contracted) */
             float ratio = width / (d + eps);                                  /* :259-260 */
             if (!(ratio < theta)) all_far = 0;                                /* :262-264 */
         }
@@ -409,7 +413,7 @@ static void bh_group(const oracle_tree *t, int start, int lanes, const float *px
                     float dx = nd->comX - px[start + k], dy = nd->comY - py[start + k];
                     float d = sqrtf(fmaf(dx, dx, dy * dy));                   /* :193-194 */
                     float sd = d > radius[start + k] ? d : radius[start + k]; /* :201-202 */
-                    float f = (G_LOCAL * nd->mass) / (sd * sd + soft * soft); /* :203-209 */
+                    float f = (G_LOCAL * nd->mass) / fmaf(sd, sd, soft * soft); /* :203-209 (contracted) */
                     float inv = 1.0f / (d + eps);                             /* :212-213 */
                     faccx[k] += (dx * inv) * f;                               /* :215-225 */
                     faccy[k] += (dy * inv) * f;
