@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["naive", "bh"], default="naive",
+                    help="naive = the BASELINE.json metric (default); bh = Barnes-Hut ms/step (BASELINE configs 4-5)")
+    ap.add_argument("--theta", type=float, default=1.0)
     args = ap.parse_args()
 
     import torch
@@ -86,12 +89,13 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = entry.load_package()
-    from nbody_amd.sharded import ShardedNaiveSim, owned_targets
+    from nbody_amd.sharded import ShardedSim, owned_targets
     O = entry.load_oracle()          # only for the synthetic inputs (seeded disc) and the cpu_baseline leg
     n = args.n
     bodies = O.init_disc(n, seed=12345)      # benchmark.cpp:317-339, seed fixed
 
-    sim = ShardedNaiveSim(pkg, n, rank, world, device=local_rank, dt=0.05, dist=dist)
+    bh = args.workload == "bh"
+    sim = ShardedSim(pkg, n, rank, world, device=local_rank, dt=0.05, dist=dist, useBarnesHut=bh, theta=args.theta)
     sim.upload(*bodies.arrays())
     my_targets = owned_targets(n, sim.spans, rank)
 
@@ -102,12 +106,19 @@ def main():
 
     sim.step(args.warmup)
     barrier()
-    sim.sim.profile(True).profile_reset()
+    # naive: per-kernel hipEvent timing stays on inside the timed region (2 launches per step, ~180 ms each).
+    # Barnes-Hut: the timed region runs the captured hipGraph (no event pairs inside a capture); the per-kernel
+    # figures come from a short eager pass AFTER it.
+    sim.sim.profile(not bh).profile_reset()
     barrier()
     t0 = time.perf_counter()
     sim.step(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    if bh:
+        sim.sim.profile(True).profile_reset()
+        sim.step(3)
+        barrier()
     force_ms, force_launches = sim.sim.profile_read(0)
     integ_ms, integ_launches = sim.sim.profile_read(1)
     if world > 1:
@@ -115,7 +126,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    if rank == 0:
+    if rank == 0 and bh:
+        build_ms, build_launches = sim.sim.profile_read(2)
+        cnt = sim.sim.bh_counters()
+        line = {
+            "metric": f"ms/step, Barnes-Hut theta={args.theta} step", "value": elapsed * 1e3 / args.steps, "unit": "ms/step",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Barnes-Hut step (tree build + COM + group-of-8 walk + Euler), N={n}, theta={args.theta}, "
+                                   f"seeded disc (benchmark.cpp:317-339, seed 12345); timed steps follow {args.warmup} warm-up "
+                                   f"steps (bodies leave the fixed root box over time, SURVEY.md §6.2)",
+                       "num_bodies": n, "parallelism": f"tree replicated, walk i-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
+                         "kernel": "bh_walk_kernel", "kernel_ms": force_ms / max(1, force_launches),
+                         "build_ms": build_ms / max(1, build_launches), "launches": int(force_launches),
+                         "node_visits_last_step": int(cnt["visits"]), "accepted_nodes_last_step": int(cnt["accepts"]),
+                         "note": "latency-bound pointer chase: 24 B per node visit, mostly L2-resident; no flop convention "
+                                 "(SURVEY.md §8d)"},
+        }
+        print(json.dumps(line), flush=True)
+    elif rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = n * float(n) * args.steps / elapsed / 1e9          # whole job: all N^2 pairs of every step
         k_ms = force_ms / max(1, force_launches)

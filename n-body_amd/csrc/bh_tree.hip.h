@@ -329,9 +329,10 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* __re
 }
 
 // 5. centre of mass, one launch per depth (deepest first) ---------------------------------------------------
-__global__ __launch_bounds__(kBhBlock) void bh_com_kernel(BhTree t, const BhCounters* __restrict__ ctr, int d)
+__global__ __launch_bounds__(kBhBlock) void bh_com_kernel(BhTree t, const BhCounters* __restrict__ ctr, int d, int min_internal)
 {
     const int c = blockIdx.x * kBhBlock + threadIdx.x;
+    if (ctr->internal <= min_internal) return;                  // done by bh_com_small_kernel
     if (c >= ctr->internal || t.depth[c] != d) return;
     const int self = t.self[c];
     float ms = 0.0f, sx = 0.0f, sy = 0.0f;
@@ -346,6 +347,34 @@ __global__ __launch_bounds__(kBhBlock) void bh_com_kernel(BhTree t, const BhCoun
     r.z = ms;
     if (ms > 0.0f) { r.x = sx / ms; r.y = sy / ms; }            // benchmark.cpp:137-141 (IEEE division)
     t.A[self] = r;
+}
+
+// Small trees: all depths in ONE launch of one workgroup (31 launches of a few microseconds each are most of a
+// Barnes-Hut step at N = 10 000).  Falls through to nothing when the tree is larger than `max_internal`.
+constexpr int kBhComBlock = 1024;
+__global__ __launch_bounds__(kBhComBlock) void bh_com_small_kernel(BhTree t, const BhCounters* __restrict__ ctr, int max_internal)
+{
+    const int I = ctr->internal;
+    if (I > max_internal) return;
+    for (int d = kBhLevels - 1; d >= 0; --d) {
+        for (int c = threadIdx.x; c < I; c += kBhComBlock) {
+            if (t.depth[c] != d) continue;
+            const int self = t.self[c];
+            float ms = 0.0f, sx = 0.0f, sy = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 a = t.A[1 + 4 * c + q];
+                ms = ms + a.z;
+                sx = __builtin_fmaf(a.x, a.z, sx);
+                sy = __builtin_fmaf(a.y, a.z, sy);
+            }
+            float4 r = t.A[self];
+            r.z = ms;
+            if (ms > 0.0f) { r.x = sx / ms; r.y = sy / ms; }
+            t.A[self] = r;
+        }
+        __syncthreads();        // one workgroup: a barrier (with its LDS/global fence) orders level d before d-1
+    }
 }
 
 // Walk --------------------------------------------------------------------------------------------------------
@@ -365,7 +394,10 @@ struct BhWalkArgs {
 __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
 {
 #pragma clang fp contract(off)   // every fma below is explicit: lanes reproduce oracle_bh_accel() bit for bit
-    __shared__ int stack[kBhStackDepth][kBhBlock];              // one private column per lane: no cross-lane traffic
+    // One stack column per GROUP of 8 lanes.  All 8 lanes of a group hold the same (node, sp) and execute the same
+    // pushes/pops, so each lane writes the value it will later read back itself (same address, same value): no
+    // cross-lane ordering is needed and 4.3 KB of LDS per workgroup leaves room for 8 waves per SIMD.
+    __shared__ int stack[kBhStackDepth][kBhBlock / 8];
     __shared__ unsigned long long red[2][kBhBlock / 64];
     const int tid = threadIdx.x;
     const int i = w.i_begin + blockIdx.x * kBhBlock + tid;
@@ -381,10 +413,13 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     const unsigned long long live_mask = __ballot(live);
     bool active = ((live_mask >> grp_shift) & 0xFFull) != 0;
     int node = 0, sp = 0;
+    float4 a = w.A[0];
+    int2 b = w.B[0];
     while (__any(active)) {
         if (active) {
-            const float4 a = w.A[node];
-            const int2 b = w.B[node];
+            // (Tried: requesting the records of both likely successors — next sibling and last child — before this
+            // node's arithmetic.  Same-box A/B: no gain at N = 10^4..65 536, 28 % slower at N = 10^6; not kept.)
+            const bool more_siblings = node != 0 && ((node - 1) & 3) != 0;
             ++visits;
             bool open = false;
             if (a.z != 0.0f) {                                  // benchmark.cpp:248
@@ -406,14 +441,17 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
                     open = true;
                 }
             }
-            const bool more_siblings = node != 0 && ((node - 1) & 3) != 0;
             if (open) {
-                if (more_siblings) stack[sp++][tid] = node - 1;
+                if (more_siblings) stack[sp++][tid >> 3] = node - 1;
                 node = b.x + 3;                                 // children pushed 0..3, popped 3..0 (:272-274, :244)
+                a = w.A[node]; b = w.B[node];
             } else if (more_siblings) {
                 node = node - 1;
+                a = w.A[node]; b = w.B[node];
             } else if (sp > 0) {
-                node = stack[--sp][tid];
+                node = stack[--sp][tid >> 3];
+                a = w.A[node];
+                b = w.B[node];
             } else {
                 active = false;
             }

@@ -70,10 +70,14 @@ struct nbody_ctx {
     int diag_blocks = 0;
     int i_begin = 0, i_end = 0;      // targets actually advanced (shard ∩ ref_compat limit)
     int i_stride = 0;
-    int variant = 0, slices = 1, k_per_lane = 2, j_per_slice = 0, blocks_x = 0, tile = 0;
+    int variant = 0, slices = 1, k_per_lane = 2, j_per_slice = 0, blocks_x = 0, tile = 0, partial_rows = 0;
     float uni_c = 0, pre_scale = 1, out_scale = 1;
     bool uploaded = false;
     Profiler prof;
+    // one captured step (hipGraph): the Barnes-Hut step is ~150 short kernels, launch-bound when enqueued eagerly
+    hipGraphExec_t step_graph = nullptr;
+    hipStream_t step_graph_stream = nullptr;
+    bool graph_failed = false;
     // Barnes-Hut state (allocated only when cfg.use_barnes_hut)
     struct Bh {
         uint64_t *keys = nullptr, *keys_sorted = nullptr, *gkeys = nullptr, *gkeys_sorted = nullptr, *keys_merged = nullptr;
@@ -218,7 +222,15 @@ int enqueue_bh_build(nbody_ctx* ctx)
     const dim3 grid_c((b.tree.cap_internal + kBhBlock - 1) / kBhBlock);
     bh_nodes_kernel<<<grid_c, blk, 0, s>>>(b.keys_merged, b.vals_merged, b.cnt, b.base, nm, ctx->m, ctx->px, ctx->py,
                                            ctx->cfg.spread, b.tree, b.ctr);
-    for (int d = kBhLevels - 1; d >= 0; --d) bh_com_kernel<<<grid_c, blk, 0, s>>>(b.tree, b.ctr, d);
+    // centre of mass: ONE single-workgroup launch covers trees of <= kComSmall internal cells (the cell count is
+    // only known on the device, so the kernels decide there which of the two paths runs); per-depth launches
+    // otherwise.  Contexts whose pool cannot exceed kComSmall cells never enqueue the per-depth launches.
+    constexpr int kComSmall = 32768;
+    const bool maybe_small = n <= 8 * kComSmall;
+    if (maybe_small) bh_com_small_kernel<<<1, kBhComBlock, 0, s>>>(b.tree, b.ctr, kComSmall);
+    if (b.tree.cap_internal > kComSmall)
+        for (int d = kBhLevels - 1; d >= 0; --d)
+            bh_com_kernel<<<grid_c, blk, 0, s>>>(b.tree, b.ctr, d, maybe_small ? kComSmall : -1);
     HIP_TRY(hipGetLastError());
     return profile_end(ctx, 2, ep);
 }
@@ -345,8 +357,6 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
     if (ctx->i_end < ctx->i_begin) ctx->i_end = ctx->i_begin;
     ctx->i_stride = ((sc + 63) / 64) * 64;
     if (ctx->i_stride < 64) ctx->i_stride = 64;
-    plan_force(ctx);
-
     auto cleanup = [&](int code) { nbody_destroy(ctx); return code; };
 #define HIP_TRY_C(expr)                                                                                   \
     do {                                                                                                  \
@@ -359,9 +369,7 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
     const size_t nb = sizeof(float) * (size_t)n;
     float** arrs[] = {&ctx->m, &ctx->px, &ctx->py, &ctx->vx, &ctx->vy, &ctx->radius, &ctx->c, &ctx->ax, &ctx->ay};
     for (float** p : arrs) HIP_TRY_C(hipMalloc((void**)p, nb));
-    const size_t pb = sizeof(float) * (size_t)kMaxSlices * ctx->i_stride;
-    HIP_TRY_C(hipMalloc((void**)&ctx->pax, pb));
-    HIP_TRY_C(hipMalloc((void**)&ctx->pay, pb));
+    // the j-slice partial rows (pax/pay) are allocated at upload, once the launch plan is known
     ctx->diag_blocks = (n + kDiagBlock - 1) / kDiagBlock;
     HIP_TRY_C(hipMalloc((void**)&ctx->diag_partials, sizeof(double) * 5 * (size_t)ctx->diag_blocks));
     HIP_TRY_C(hipMemset(ctx->ax, 0, nb));
@@ -410,6 +418,7 @@ void nbody_destroy(nbody_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->step_graph) (void)hipGraphExecDestroy(ctx->step_graph);
     float* arrs[] = {ctx->m, ctx->px, ctx->py, ctx->vx, ctx->vy, ctx->radius, ctx->c, ctx->ax, ctx->ay, ctx->pax, ctx->pay};
     for (float* p : arrs)
         if (p) (void)hipFree(p);
@@ -473,6 +482,22 @@ int nbody_upload(nbody_ctx* ctx, const float* m, const float* posX, const float*
     ctx->pre_scale = variant == kScaled ? 1.0f / r0 : 1.0f;
     ctx->out_scale = variant == kScaled ? m[0] / (r0 * r0) : (variant == kUniform ? m[0] : 1.0f);
     plan_force(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->step_graph) {                       // buffers may move below: re-capture on the next step
+        (void)hipGraphExecDestroy(ctx->step_graph);
+        ctx->step_graph = nullptr;
+    }
+    const int rows = ctx->cfg.use_barnes_hut ? 1 : ctx->slices;
+    if (rows > ctx->partial_rows) {
+        if (ctx->pax) HIP_TRY(hipFree(ctx->pax));
+        if (ctx->pay) HIP_TRY(hipFree(ctx->pay));
+        ctx->pax = ctx->pay = nullptr;
+        ctx->partial_rows = 0;
+        const size_t pb = sizeof(float) * (size_t)rows * ctx->i_stride;
+        HIP_TRY(hipMalloc((void**)&ctx->pax, pb));
+        HIP_TRY(hipMalloc((void**)&ctx->pay, pb));
+        ctx->partial_rows = rows;
+    }
     std::vector<float> c((size_t)n);
     for (int i = 0; i < n; ++i)
         c[i] = variant == kExact ? radius[i] * radius[i] : 1.0f / (radius[i] * radius[i] + kSoft2);
@@ -492,18 +517,77 @@ int nbody_upload(nbody_ctx* ctx, const float* m, const float* posX, const float*
     return NBODY_OK;
 }
 
+namespace {
+
+int enqueue_one_step(nbody_ctx* ctx);
+
+void drop_step_graph(nbody_ctx* ctx)
+{
+    if (ctx->step_graph) (void)hipGraphExecDestroy(ctx->step_graph);
+    ctx->step_graph = nullptr;
+    ctx->step_graph_stream = nullptr;
+}
+
+// Capture one step into a hipGraph (Barnes-Hut only; skipped while per-kernel event timing is on, because
+// event pairs recorded inside a capture cannot be queried).  Any failure falls back to eager launches for good.
+bool ensure_step_graph(nbody_ctx* ctx)
+{
+    if (!ctx->cfg.use_barnes_hut || ctx->prof.on || ctx->graph_failed || std::getenv("NBODY_NO_GRAPH")) return false;
+    if (ctx->step_graph && ctx->step_graph_stream == ctx->stream) return true;
+    drop_step_graph(ctx);
+    hipGraph_t graph = nullptr;
+    const bool dbg = std::getenv("NBODY_DEBUG") != nullptr;
+    const hipError_t be = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+    if (be != hipSuccess) {
+        if (dbg) std::fprintf(stderr, "[nbody] graph: begin capture failed: %s\n", hipGetErrorString(be));
+        ctx->graph_failed = true;
+        (void)hipGetLastError();
+        return false;
+    }
+    const int rc = enqueue_one_step(ctx);
+    const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    if (dbg) std::fprintf(stderr, "[nbody] graph: capture rc=%d (%s) end=%s graph=%p\n", rc, rc ? g_err : "ok", hipGetErrorString(e), (void*)graph);
+    if (rc != NBODY_OK || e != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        ctx->graph_failed = true;
+        return false;
+    }
+    const hipError_t ie = hipGraphInstantiate(&ctx->step_graph, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) { ctx->step_graph = nullptr; ctx->graph_failed = true; (void)hipGetLastError(); return false; }
+    ctx->step_graph_stream = ctx->stream;
+    return true;
+}
+
+}  // namespace
+
 int nbody_step(nbody_ctx* ctx, int32_t nsteps)
 {
     if (!ctx) return fail(NBODY_ERR_INVALID, "nbody_step: null context");
     if (!ctx->uploaded) return fail(NBODY_ERR_INVALID, "nbody_step: nbody_upload has not been called");
     if (nsteps < 0) return fail(NBODY_ERR_INVALID, "nbody_step: nsteps=%d", nsteps);
     HIP_TRY(hipSetDevice(ctx->device));
+    if (nsteps > 0 && ensure_step_graph(ctx)) {
+        for (int s = 0; s < nsteps; ++s) HIP_TRY(hipGraphLaunch(ctx->step_graph, ctx->stream));
+        return NBODY_OK;
+    }
     for (int s = 0; s < nsteps; ++s) {
+        const int rc = enqueue_one_step(ctx);
+        if (rc) return rc;
+    }
+    return NBODY_OK;
+}
+
+namespace {
+int enqueue_one_step(nbody_ctx* ctx)
+{
+    {
         int rc;
         if (ctx->cfg.use_barnes_hut) {
             rc = enqueue_bh_build(ctx);                      // benchmark.cpp:357
             if (rc) return rc;
-            if (!ctx->cfg.use_parallel) continue;            // benchmark.cpp:359: tree built, nothing else happens
+            if (!ctx->cfg.use_parallel) return NBODY_OK;     // benchmark.cpp:359: tree built, nothing else happens
             rc = enqueue_bh_walk(ctx);                       // :365-380
         } else {
             rc = enqueue_force(ctx);                         // :407-478
@@ -514,6 +598,7 @@ int nbody_step(nbody_ctx* ctx, int32_t nsteps)
     }
     return NBODY_OK;
 }
+}  // namespace
 
 int nbody_compute_accel(nbody_ctx* ctx)
 {

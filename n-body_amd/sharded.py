@@ -30,15 +30,17 @@ def exchange_slices(tensors, spans, rank, dist, group=None):
                 dist.broadcast(t[b:b + c], src=src, group=group)
 
 
-class ShardedNaiveSim:
-    """One rank's share of a sharded naive simulation on its GPU."""
+class ShardedSim:
+    """One rank's share of a sharded simulation (naive or Barnes-Hut) on its GPU.  In Barnes-Hut mode every rank
+    rebuilds the (cheap) tree from the gathered positions and walks it for its own targets only."""
 
-    def __init__(self, pkg, num_bodies, rank, world, *, device, dt=0.05, ref_compat=True, dist=None, **kw):
+    def __init__(self, pkg, num_bodies, rank, world, *, device, dt=0.05, ref_compat=True, dist=None,
+                 useBarnesHut=False, **kw):
         import torch
         self.torch, self.dist = torch, dist
         self.rank, self.world, self.n = rank, world, num_bodies
         self.spans = [pkg.shard_range(num_bodies, world, r) for r in range(world)]
-        self.sim = pkg.NBodySim(num_bodies, dt=dt, useBarnesHut=False, ref_compat=ref_compat, device=device,
+        self.sim = pkg.NBodySim(num_bodies, dt=dt, useBarnesHut=useBarnesHut, ref_compat=ref_compat, device=device,
                                 shard=self.spans[rank], **kw)
         self.device = torch.device("cuda", device)
         # order the library's kernels and torch's collectives on the same stream
@@ -67,6 +69,9 @@ class ShardedNaiveSim:
     def close(self):
         self._pos = None
         self.sim.close()
+
+
+ShardedNaiveSim = ShardedSim      # earlier name
 
 
 def owned_targets(num_bodies, spans, rank, ref_compat=True):

@@ -198,3 +198,20 @@ def test_n1m_tree_and_walk(nb, O):
     nx, ny = O.naive_accel_f64_subset(b, idx)
     en = rel_err(ax[idx], ay[idx], nx, ny)
     assert 0.01 < np.median(en) < 0.08                                 # 3.2-4.4 % at theta = 1
+
+
+def test_clustered_plummer_theta05(nb, O):
+    """BASELINE config 5 flavour (clustered 2-D Plummer, theta = 0.5) at a CPU-checkable size.  The reference has no
+    Plummer generator: the build's own (oracle.init_plummer) feeds BOTH sides, and the comparison is
+    again exact; accuracy vs f64 naive must be in the theta = 0.5 band of SURVEY.md row A7 (median < 1 %)."""
+    n = 65536
+    b = O.init_plummer(n, scale=50.0, seed=4)
+    ax, ay, _, tree, cnt = gpu_bh(nb, b, theta=0.5, want_tree=True)
+    ot = O.Tree(n).build(b, 400.0)
+    assert len(tree) == ot.nodes_used
+    ox, oy, ocnt = ot.accel(b, 0.5)
+    assert cnt == ocnt
+    assert np.array_equal(ax, ox.astype(np.float32)) and np.array_equal(ay, oy.astype(np.float32))
+    idx = np.arange(0, n, 257, dtype=np.int32)
+    nx, ny = O.naive_accel_f64_subset(b, idx)
+    assert np.median(rel_err(ax[idx], ay[idx], nx, ny)) < 0.01
