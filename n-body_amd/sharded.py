@@ -12,16 +12,20 @@ torch is plumbing here (process group, stream ordering); the physics runs in the
 import numpy as np
 
 
-def exchange_slices(tensors, spans, rank, dist, group=None):
-    """All-gather in place: every rank contributes tensors[k][begin:begin+count] of ITS span.
+def exchange_slices(tensors, spans, rank, dist, group=None, staging=None):
+    """All-gather: every rank contributes tensors[k][begin:begin+count] of ITS span; afterwards every rank holds
+    every span.
 
-    Equal spans -> one all_gather_into_tensor per array (in place, the input is a view of the output);
-    ragged spans (N not divisible) -> one broadcast per rank and array."""
+    Equal spans -> one all_gather_into_tensor per array into a staging buffer of the same shape, copied back
+    (the send buffer is a slice of the array itself, and an aliased in-place gather is not something every
+    backend promises); ragged spans (N not divisible) -> one broadcast per rank and array."""
     counts = {c for _, c in spans}
     if len(counts) == 1 and spans[0][1] * len(spans) == tensors[0].numel():
         b, c = spans[rank]
-        for t in tensors:
-            dist.all_gather_into_tensor(t, t[b:b + c], group=group)
+        for k, t in enumerate(tensors):
+            stage = staging[k] if staging is not None else t.new_empty(t.shape)
+            dist.all_gather_into_tensor(stage, t[b:b + c].contiguous(), group=group)
+            t.copy_(stage)
     else:
         for src, (b, c) in enumerate(spans):
             if c == 0:
@@ -43,25 +47,31 @@ class ShardedSim:
         self.sim = pkg.NBodySim(num_bodies, dt=dt, useBarnesHut=useBarnesHut, ref_compat=ref_compat, device=device,
                                 shard=self.spans[rank], **kw)
         self.device = torch.device("cuda", device)
-        # order the library's kernels and torch's collectives on the same stream
-        self.sim.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        # One dedicated (non-default) stream carries BOTH the library's kernels and torch's collectives, so the
+        # all-gather is ordered after the integrate kernel and before the next force kernel without host syncs.
+        # (The default stream's handle is 0, which nbody_set_stream reads as "use the context's own stream".)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.sim.set_stream(self.stream.cuda_stream)
         self._pos = None
+        self._stage = None
 
     def upload(self, m, posX, posY, velX, velY, radius):
         self.sim.upload(m, posX, posY, velX, velY, radius)
         t = self.torch
         self._pos = [t.as_tensor(self.sim.device_array(k), device=self.device) for k in ("posX", "posY")]
+        self._stage = [t.empty_like(p) for p in self._pos] if self.world > 1 else None
         return self
 
     def step(self, nsteps=1):
         for _ in range(nsteps):
             self.sim.step(1)                               # force over all sources + Euler on the owned shard
             if self.world > 1:
-                exchange_slices(self._pos, self.spans, self.rank, self.dist)
+                with self.torch.cuda.stream(self.stream):
+                    exchange_slices(self._pos, self.spans, self.rank, self.dist, staging=self._stage)
         return self
 
     def sync(self):
-        self.torch.cuda.synchronize(self.device)
+        self.stream.synchronize()
 
     def targets(self):
         return self.spans[self.rank]

@@ -303,15 +303,20 @@ def test_sharded_driver_torch_plumbing(nb, O):
     n = 4096
     b = O.init_disc(n, seed=5)
     _, _, ref, _ = run_gpu(nb, b, nsteps=2)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    import socket
+    with socket.socket() as sk:                      # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         sim = ShardedNaiveSim(nb, n, 0, 1, device=0, dt=0.05, dist=dist)
         sim.upload(*b.arrays())
         sim.step(2)
-        exchange_slices(sim._pos, sim.spans, 0, dist)          # world=1: the collective itself, in place
+        with torch.cuda.stream(sim.stream):                    # world=1: the collective itself, on the shared stream
+            exchange_slices(sim._pos, sim.spans, 0, dist)
         sim.sync()
         px = sim._pos[0].cpu().numpy()
         st = sim.sim.download()
