@@ -110,8 +110,8 @@ __device__ __forceinline__ f2 pair_weight(const f2 d2, const f2 ci, const Src<V>
 // i_begin + b*kBlock*K + k*kBlock + tid (lane-contiguous => coalesced) against the sources of slice y.
 // K targets per lane are held as K/2 packed pairs; JU sources are processed per inner iteration in
 // stage order (all dx/dy, all d2, all rsq, ...) so no dependent instructions sit back to back.
-template <int V, int K, int JU, int TJ>
-__global__ __launch_bounds__(kBlock, 4) void force_naive_kernel(const ForceArgs a)
+template <int V, int K, int JU, int TJ, int MINW = 4>
+__global__ __launch_bounds__(kBlock, MINW) void force_naive_kernel(const ForceArgs a)
 {
     using S = Src<V>;
     constexpr int KP = K / 2, G = JU * KP;
