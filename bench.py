@@ -64,12 +64,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=1 << 20)
+    ap.add_argument("--bodies", "--n", dest="n", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["naive", "bh"], default="naive",
                     help="naive = the BASELINE.json metric (default); bh = Barnes-Hut ms/step (BASELINE configs 4-5)")
     ap.add_argument("--theta", type=float, default=1.0)
     args = ap.parse_args()
+    if os.environ.get("NBODY_DEBUG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("NBODY_DEBUG_TIMEOUT", "90")), exit=True)
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))

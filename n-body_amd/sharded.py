@@ -54,6 +54,11 @@ class ShardedSim:
         self.sim.set_stream(self.stream.cuda_stream)
         self._pos = None
         self._stage = None
+        # RCCL collectives are stream-ordered device work.  Host-staged backends (gloo: the CPU tests and the
+        # one-GPU rehearsal) copy through pinned memory from a helper thread; torch 2.10/ROCm 7 was seen to stall
+        # there when the helper's stream had to wait on a still-busy compute stream (tools/dist_probe.py), so for
+        # those backends the stream is drained on the host first.
+        self._host_staged = dist is not None and world > 1 and dist.get_backend() != "nccl"
 
     def upload(self, m, posX, posY, velX, velY, radius):
         self.sim.upload(m, posX, posY, velX, velY, radius)
@@ -66,9 +71,14 @@ class ShardedSim:
         for _ in range(nsteps):
             self.sim.step(1)                               # force over all sources + Euler on the owned shard
             if self.world > 1:
-                with self.torch.cuda.stream(self.stream):
-                    exchange_slices(self._pos, self.spans, self.rank, self.dist, staging=self._stage)
+                self.exchange()
         return self
+
+    def exchange(self):
+        if self._host_staged:
+            self.stream.synchronize()
+        with self.torch.cuda.stream(self.stream):
+            exchange_slices(self._pos, self.spans, self.rank, self.dist, staging=self._stage)
 
     def sync(self):
         self.stream.synchronize()

@@ -3,11 +3,9 @@ bench.py uses (nbody_amd.sharded.ShardedSim: shard plan from the C-ABI, library 
 torch stream, staged all-gather).  The test box has one GPU, so the ranks share it and talk over `gloo`
 (NBODY_DIST_BACKEND); on the 8-GPU node the only difference is backend="nccl" (RCCL) and one device per rank.
 
-Only the naive path is rehearsed this way.  Barnes-Hut shards through the very same driver (and is covered on one
-context per shard by test_gpu_bh.py::test_two_shards_equal_one), but with TWO PROCESSES TIME-SLICING ONE GPU its
-step stalled intermittently in this rehearsal (both ranks waiting in the all-gather for their own stream; the
-hipcub scan/sort it launches use decoupled look-back spin-waits between workgroups, the naive path launches none).
-One process per GPU — the supported deployment — does not share a device, so the case is not kept in the suite."""
+Both paths are rehearsed.  With a host-staged backend (gloo) ShardedSim drains its stream before each exchange:
+gloo's helper thread stalled when its private stream had to wait on a still-busy compute stream (reproduced in ONE
+process by tools/dist_probe.py; the RCCL path, stream-ordered device work, ran the same probe cleanly)."""
 import os
 import socket
 import subprocess
@@ -26,7 +24,7 @@ def free_port():
         return sk.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,n,bh", [(2, 8192, 0), (3, 5000, 0)])
+@pytest.mark.parametrize("world,n,bh", [(2, 8192, 0), (3, 5000, 0), (2, 8192, 1)])
 def test_sharded_ranks_equal_single_context(nb, O, tmp_path, world, n, bh):
     nsteps = 3
     env = dict(os.environ, NBODY_DIST_BACKEND="gloo", OMP_NUM_THREADS="2")
@@ -55,7 +53,7 @@ def test_bench_two_ranks_prints_one_json_line(tmp_path):
     env = dict(os.environ, NBODY_DIST_BACKEND="gloo", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--n", "131072"]
+           "--bodies", "131072"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
