@@ -59,7 +59,11 @@ typedef struct nbody_config {
                                 uniform power-of-two radius >= 4 (pre-scaled coordinates, the reference's
                                 only case: R = 8), 2 = uniform mass+radius >= 4, 3 = per-body mass and
                                 radius >= 4, 4 = exact-general (any radius)                              */
-    int32_t reserved[4];
+    int32_t adaptive_box;    /* Barnes-Hut only.  0 (default, the reference): fixed root box [-spread,spread]^2, bodies
+                                outside it exert no force (benchmark.cpp:83-85,169).  1 (opt-in, no reference
+                                counterpart): every step the root box is [-h,h]^2 with
+                                h = max_i max(|x_i|,|y_i|) over all finite positions, so no body escapes the tree */
+    int32_t reserved[3];
 } nbody_config;
 
 /* Defaults = benchmark.cpp:300-306 (BH on, n=10000, spread=400, mass=1000, theta=1, dt=0.05). */
@@ -81,8 +85,8 @@ int nbody_upload(nbody_ctx *ctx, const float *m, const float *posX, const float 
                  const float *velX, const float *velY, const float *radius);
 
 /* Enqueue nsteps iterations of the block benchmark.cpp:354-511 (force + forward Euler).  Returns
-   once enqueued.  In a sharded context only the owned i-range is advanced; the caller must call
-   nbody_exchange_* (or its own all-gather on nbody_device_ptr) between steps, so nsteps must be 1. */
+   once enqueued.  In a sharded context only the owned i-range is advanced; the caller all-gathers the
+   position arrays (nbody_device_ptr) between steps, so nsteps must be 1 there. */
 int nbody_step(nbody_ctx *ctx, int32_t nsteps);
 
 /* Only the force phase (accelerations of the current positions), no integration. */
@@ -92,6 +96,16 @@ int nbody_sync(nbody_ctx *ctx);
 
 /* Copies the state back (syncs).  Any pointer may be NULL.  main.cpp:650-653 needs posX/posY only. */
 int nbody_download(nbody_ctx *ctx, float *posX, float *posY, float *velX, float *velY);
+
+/* Position streaming for a viewer (the consumer is the per-frame draw loop main.cpp:646-655,
+   which reads posX/posY only).  nbody_frame_publish enqueues, behind the steps enqueued so far, a device-side
+   snapshot of posX/posY and its asynchronous copy into library-owned PINNED host memory on a separate copy
+   stream; it returns at once and later steps do not wait for the copy.  nbody_frame_acquire blocks until the
+   OLDEST published, not yet acquired frame has landed and returns its arrays (length num_bodies) and the step
+   count it shows; the pointers stay valid until two further frames have been published.  At most 2 frames may
+   be in flight: a third publish without an acquire fails with NBODY_ERR_INVALID. */
+int nbody_frame_publish(nbody_ctx *ctx);
+int nbody_frame_acquire(nbody_ctx *ctx, const float **posX, const float **posY, int64_t *step_index);
 
 /* Parity hook: the accelerations evaluated by the last nbody_step / nbody_compute_accel, i.e. the
    reference's tmp_accX/tmp_accY (benchmark.cpp:412-413, 476-477).  Entries outside the owned shard

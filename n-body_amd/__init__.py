@@ -21,7 +21,8 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 # every symbol include/nbody.h declares
 ABI_SYMBOLS = (
     "nbody_default_config", "nbody_shard_range", "nbody_create", "nbody_destroy", "nbody_set_stream",
-    "nbody_upload", "nbody_step", "nbody_compute_accel", "nbody_sync", "nbody_download", "nbody_get_accel",
+    "nbody_upload", "nbody_step", "nbody_compute_accel", "nbody_sync", "nbody_download", "nbody_frame_publish",
+    "nbody_frame_acquire", "nbody_get_accel",
     "nbody_diagnostics", "nbody_device_ptr", "nbody_profile_enable", "nbody_profile_read",
     "nbody_profile_reset", "nbody_get_info", "nbody_bh_tree_nodes", "nbody_bh_counters",
     "nbody_last_error", "nbody_abi_version",
@@ -33,7 +34,7 @@ class Config(C.Structure):
     _fields_ = [("num_bodies", C.c_int32), ("spread", C.c_float), ("mass", C.c_float), ("dt", C.c_float),
                 ("theta", C.c_float), ("use_barnes_hut", C.c_int32), ("use_parallel", C.c_int32),
                 ("ref_compat", C.c_int32), ("device", C.c_int32), ("shard_begin", C.c_int32),
-                ("shard_count", C.c_int32), ("force_variant", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("shard_count", C.c_int32), ("force_variant", C.c_int32), ("adaptive_box", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class NBodyError(RuntimeError):
@@ -65,6 +66,8 @@ def lib():
         L.nbody_compute_accel.argtypes = [C.c_void_p]
         L.nbody_sync.argtypes = [C.c_void_p]
         L.nbody_download.argtypes = [C.c_void_p] + [_f32p] * 4
+        L.nbody_frame_publish.argtypes = [C.c_void_p]
+        L.nbody_frame_acquire.argtypes = [C.c_void_p, C.POINTER(_f32p), C.POINTER(_f32p), C.POINTER(C.c_int64)]
         L.nbody_get_accel.argtypes = [C.c_void_p, _f32p, _f32p]
         L.nbody_diagnostics.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.nbody_device_ptr.argtypes = [C.c_void_p, C.c_int32]
@@ -127,11 +130,12 @@ class NBodySim:
     (benchmark.cpp:300-306) and loop body (benchmark.cpp:354-511)."""
 
     def __init__(self, numBodies, *, spread=400.0, mass=1000.0, dt=0.05, theta=1.0, useBarnesHut=False,
-                 useParallel=True, ref_compat=True, device=-1, shard=None, force_variant=0):
+                 useParallel=True, ref_compat=True, device=-1, shard=None, force_variant=0, adaptive_box=False):
         cfg = default_config()
         cfg.num_bodies, cfg.spread, cfg.mass, cfg.dt, cfg.theta = int(numBodies), spread, mass, dt, theta
         cfg.use_barnes_hut, cfg.use_parallel = int(bool(useBarnesHut)), int(bool(useParallel))
         cfg.ref_compat, cfg.device, cfg.force_variant = int(bool(ref_compat)), int(device), int(force_variant)
+        cfg.adaptive_box = int(bool(adaptive_box))
         if shard is not None:
             cfg.shard_begin, cfg.shard_count = int(shard[0]), int(shard[1])
         self.cfg = cfg
@@ -150,6 +154,19 @@ class NBodySim:
         out = [np.empty(self.n, np.float32) for _ in range(4)]
         _check(lib().nbody_download(self._h, *[_ptr(a) for a in out]))
         return dict(posX=out[0], posY=out[1], velX=out[2], velY=out[3])
+
+    # -- position streaming for a viewer (main.cpp:646-655 reads posX/posY every frame) -----------
+    def frame_publish(self):
+        """Enqueue an asynchronous snapshot of posX/posY (after the steps enqueued so far) into pinned host memory."""
+        _check(lib().nbody_frame_publish(self._h))
+        return self
+
+    def frame_acquire(self):
+        """Wait for the oldest outstanding frame: (posX, posY, step) — zero-copy views of library-owned pinned
+        memory, valid until two further frames have been published."""
+        px, py, step = _f32p(), _f32p(), C.c_int64()
+        _check(lib().nbody_frame_acquire(self._h, C.byref(px), C.byref(py), C.byref(step)))
+        return (np.ctypeslib.as_array(px, shape=(self.n,)), np.ctypeslib.as_array(py, shape=(self.n,)), step.value)
 
     def accel(self):
         ax, ay = np.empty(self.n, np.float32), np.empty(self.n, np.float32)

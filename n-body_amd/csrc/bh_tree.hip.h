@@ -56,6 +56,8 @@ struct BhCounters {          // device-resident scalars of one build/walk
     int overflow;            // node pool (1) or tie-instance buffer (2) too small
     int ghosts;              // G: second instances of bodies on split lines
     unsigned long long visits, accepts;
+    float root_half;         // half-width h of the root box [-h,h]^2 of this build (= spread unless adaptive)
+    int pad_;
 };
 
 // walk record of a node: A = {comX, comY, mass, width}, B = {childBase (-1: leaf), bodyIndex (-1: none)}
@@ -77,11 +79,12 @@ __device__ __forceinline__ int bh_lcp_levels(uint64_t a, uint64_t b)
 
 // 1. path keys ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBhBlock) void bh_keys_kernel(const float* __restrict__ px, const float* __restrict__ py,
-                                                           int n, float spread, uint64_t* __restrict__ keys,
-                                                           int* __restrict__ vals)
+                                                           int n, const BhCounters* __restrict__ ctr,
+                                                           uint64_t* __restrict__ keys, int* __restrict__ vals)
 {
     const int i = blockIdx.x * kBhBlock + threadIdx.x;
     if (i >= n) return;
+    const float spread = ctr->root_half;
     const float x = px[i], y = py[i];
     float tlx = -spread, tly = -spread, brx = spread, bry = spread;
     uint64_t key;
@@ -114,15 +117,39 @@ __global__ void bh_valid_kernel(const uint64_t* __restrict__ keys, int n, BhCoun
     ctr->valid = lo;
 }
 
-__global__ void bh_reset_kernel(BhCounters* __restrict__ ctr)
+// root_half0: the fixed box (spread), or a tiny positive floor that bh_bounds_kernel raises (adaptive box)
+__global__ void bh_reset_kernel(BhCounters* __restrict__ ctr, float root_half0)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ctr->root_half = root_half0;
     ctr->valid = 0;
     ctr->internal = 0;
     ctr->overflow = 0;
     ctr->ghosts = 0;
     ctr->visits = 0;
     ctr->accepts = 0;
+}
+
+// Adaptive root box (opt-in, nbody_config.adaptive_box): h = max_i max(|x_i|,|y_i|) over finite positions.
+// Non-negative floats order like their bit patterns, so the cross-workgroup maximum is an integer atomicMax.
+__global__ __launch_bounds__(kBhBlock) void bh_bounds_kernel(const float* __restrict__ px, const float* __restrict__ py, int n,
+                                                             BhCounters* __restrict__ ctr)
+{
+    float h = 0.0f;
+    for (int i = blockIdx.x * kBhBlock + threadIdx.x; i < n; i += gridDim.x * kBhBlock) {
+        const float ax = fabsf(px[i]), ay = fabsf(py[i]);
+        if (ax < __builtin_huge_valf()) h = fmaxf(h, ax);      // false for inf and NaN
+        if (ay < __builtin_huge_valf()) h = fmaxf(h, ay);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h = fmaxf(h, __shfl_xor(h, o));
+    __shared__ float part[kBhBlock / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBhBlock / 64; ++w) h = fmaxf(h, part[w]);
+        atomicMax(reinterpret_cast<int*>(&ctr->root_half), __float_as_int(h));
+    }
 }
 
 // One descent with the reference's float arithmetic.  force_level/force_axis: take the UPPER child on that axis
@@ -152,12 +179,13 @@ __device__ __forceinline__ uint64_t bh_descend(float x, float y, float spread, i
 // 2b. second instances.  Runs on the sorted primaries; leaf depth of body i = 1 + max(lcp with its neighbours).
 __global__ __launch_bounds__(kBhBlock) void bh_ties_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
                                                            const float* __restrict__ px, const float* __restrict__ py,
-                                                           float spread, BhCounters* __restrict__ ctr,
+                                                           BhCounters* __restrict__ ctr,
                                                            uint64_t* __restrict__ gkeys, int* __restrict__ gvals, int gcap)
 {
     const int i = blockIdx.x * kBhBlock + threadIdx.x;
     const int M = ctr->valid;
     if (i >= M) return;
+    const float spread = ctr->root_half;
     const uint64_t k = keys[i];
     const int lp = i > 0 ? bh_lcp_levels(keys[i - 1], k) : -1;
     const int ln = i + 1 < M ? bh_lcp_levels(k, keys[i + 1]) : -1;
@@ -242,11 +270,12 @@ __device__ __forceinline__ int bh_lower_bound(const uint64_t* __restrict__ keys,
 __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
                                                             const int* __restrict__ cnt, const int* __restrict__ base, int n,
                                                             const float* __restrict__ m, const float* __restrict__ px,
-                                                            const float* __restrict__ py, float spread, BhTree t,
+                                                            const float* __restrict__ py, BhTree t,
                                                             BhCounters* __restrict__ ctr)
 {
     const int c = blockIdx.x * kBhBlock + threadIdx.x;
     const int M = ctr->valid;
+    const float spread = ctr->root_half;
     const int I = M >= 2 ? base[M - 1] + cnt[M - 1] : 0;
     if (c == 0) {
         ctr->internal = I < t.cap_internal ? I : t.cap_internal;

@@ -73,7 +73,19 @@ struct nbody_ctx {
     int variant = 0, slices = 1, k_per_lane = 2, j_per_slice = 0, blocks_x = 0, tile = 0, partial_rows = 0;
     float uni_c = 0, pre_scale = 1, out_scale = 1;
     bool uploaded = false;
+    int64_t steps_enqueued = 0;      // since the last upload
     Profiler prof;
+    // position streaming (nbody_frame_*): device snapshots + pinned host frames, copied on their own stream
+    struct Frames {
+        static constexpr int kSlots = 2;
+        float* dev[kSlots] = {nullptr, nullptr};      // [2n]: x then y
+        float* host[kSlots] = {nullptr, nullptr};     // pinned, same layout
+        hipEvent_t snapped[kSlots] = {nullptr, nullptr}, landed[kSlots] = {nullptr, nullptr};
+        int64_t step[kSlots] = {0, 0};
+        hipStream_t copy_stream = nullptr;
+        int64_t published = 0, acquired = 0;
+        bool ready = false;
+    } frames;
     // one captured step (hipGraph): the Barnes-Hut step is ~150 short kernels, launch-bound when enqueued eagerly
     hipGraphExec_t step_graph = nullptr;
     hipStream_t step_graph_stream = nullptr;
@@ -203,14 +215,15 @@ int enqueue_bh_build(nbody_ctx* ctx)
     if (rc) return rc;
     const int nm = n + b.gcap;                                 // instances after the merge (tail = padding)
     const dim3 grid_g((b.gcap + kBhBlock - 1) / kBhBlock), grid_m((nm + kBhBlock - 1) / kBhBlock);
-    bh_reset_kernel<<<1, 64, 0, s>>>(b.ctr);
-    bh_keys_kernel<<<grid_n, blk, 0, s>>>(ctx->px, ctx->py, n, ctx->cfg.spread, b.keys, b.vals);
+    const bool adaptive = ctx->cfg.adaptive_box != 0;
+    bh_reset_kernel<<<1, 64, 0, s>>>(b.ctr, adaptive ? 1e-30f : ctx->cfg.spread);
+    if (adaptive) bh_bounds_kernel<<<dim3(grid_n.x < 1024u ? grid_n.x : 1024u), blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr);
+    bh_keys_kernel<<<grid_n, blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr, b.keys, b.vals);
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, b.keys, b.keys_sorted, b.vals, b.vals_sorted, n,
                                                0, 64, s));
     bh_valid_kernel<<<1, 64, 0, s>>>(b.keys_sorted, n, b.ctr);
     // bodies exactly on a split line get a second instance (inclusive bounds, benchmark.cpp:83-85)
-    bh_ties_kernel<<<grid_n, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, ctx->cfg.spread, b.ctr, b.gkeys,
-                                          b.gvals, b.gcap);
+    bh_ties_kernel<<<grid_n, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.ctr, b.gkeys, b.gvals, b.gcap);
     bh_ghost_pad_kernel<<<grid_g, blk, 0, s>>>(b.ctr, b.gkeys, b.gvals, b.gcap);
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.gsort_tmp, b.gsort_bytes, b.gkeys, b.gkeys_sorted, b.gvals, b.gvals_sorted,
                                                b.gcap, 0, 64, s));
@@ -221,7 +234,7 @@ int enqueue_bh_build(nbody_ctx* ctx)
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b.scan_tmp, b.scan_bytes, b.cnt, b.base, nm, s));
     const dim3 grid_c((b.tree.cap_internal + kBhBlock - 1) / kBhBlock);
     bh_nodes_kernel<<<grid_c, blk, 0, s>>>(b.keys_merged, b.vals_merged, b.cnt, b.base, nm, ctx->m, ctx->px, ctx->py,
-                                           ctx->cfg.spread, b.tree, b.ctr);
+                                           b.tree, b.ctr);
     // centre of mass: ONE single-workgroup launch covers trees of <= kComSmall internal cells (the cell count is
     // only known on the device, so the kernels decide there which of the two paths runs); per-depth launches
     // otherwise.  Contexts whose pool cannot exceed kComSmall cells never enqueue the per-depth launches.
@@ -333,7 +346,7 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
         return fail(NBODY_ERR_INVALID, "nbody_create: shard [%d,+%d) outside [0,%d)", cfg->shard_begin, cfg->shard_count, n);
     if (cfg->force_variant < 0 || cfg->force_variant > 4)
         return fail(NBODY_ERR_INVALID, "nbody_create: force_variant=%d", cfg->force_variant);
-    if (cfg->use_barnes_hut && !(cfg->spread > 0.0f))
+    if (cfg->use_barnes_hut && !cfg->adaptive_box && !(cfg->spread > 0.0f))
         return fail(NBODY_ERR_INVALID, "nbody_create: Barnes-Hut needs spread > 0 (root box), got %g", cfg->spread);
     if (cfg->use_barnes_hut && cfg->shard_begin % 8 != 0)
         return fail(NBODY_ERR_INVALID, "nbody_create: Barnes-Hut shards must start on a multiple of 8 (groups of 8 bodies)");
@@ -433,6 +446,16 @@ void nbody_destroy(nbody_ctx* ctx)
     }
     for (auto& pool : ctx->prof.pool)
         for (auto& ep : pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    {
+        auto& f = ctx->frames;
+        if (f.copy_stream) { (void)hipStreamSynchronize(f.copy_stream); (void)hipStreamDestroy(f.copy_stream); }
+        for (int k = 0; k < nbody_ctx::Frames::kSlots; ++k) {
+            if (f.dev[k]) (void)hipFree(f.dev[k]);
+            if (f.host[k]) (void)hipHostFree(f.host[k]);
+            if (f.snapped[k]) (void)hipEventDestroy(f.snapped[k]);
+            if (f.landed[k]) (void)hipEventDestroy(f.landed[k]);
+        }
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -514,6 +537,11 @@ int nbody_upload(nbody_ctx* ctx, const float* m, const float* posX, const float*
     HIP_TRY(hipMemset(ctx->ax, 0, nb));
     HIP_TRY(hipMemset(ctx->ay, 0, nb));
     ctx->uploaded = true;
+    ctx->steps_enqueued = 0;
+    if (ctx->frames.ready) {                     // frames of the previous state are dropped
+        HIP_TRY(hipStreamSynchronize(ctx->frames.copy_stream));
+        ctx->frames.acquired = ctx->frames.published;
+    }
     return NBODY_OK;
 }
 
@@ -569,12 +597,16 @@ int nbody_step(nbody_ctx* ctx, int32_t nsteps)
     if (nsteps < 0) return fail(NBODY_ERR_INVALID, "nbody_step: nsteps=%d", nsteps);
     HIP_TRY(hipSetDevice(ctx->device));
     if (nsteps > 0 && ensure_step_graph(ctx)) {
-        for (int s = 0; s < nsteps; ++s) HIP_TRY(hipGraphLaunch(ctx->step_graph, ctx->stream));
+        for (int s = 0; s < nsteps; ++s) {
+            HIP_TRY(hipGraphLaunch(ctx->step_graph, ctx->stream));
+            ++ctx->steps_enqueued;
+        }
         return NBODY_OK;
     }
     for (int s = 0; s < nsteps; ++s) {
         const int rc = enqueue_one_step(ctx);
         if (rc) return rc;
+        ++ctx->steps_enqueued;
     }
     return NBODY_OK;
 }
@@ -646,6 +678,58 @@ int nbody_download(nbody_ctx* ctx, float* posX, float* posY, float* velX, float*
     if (posY) HIP_TRY(hipMemcpy(posY, ctx->py, nb, hipMemcpyDeviceToHost));
     if (velX) HIP_TRY(hipMemcpy(velX, ctx->vx, nb, hipMemcpyDeviceToHost));
     if (velY) HIP_TRY(hipMemcpy(velY, ctx->vy, nb, hipMemcpyDeviceToHost));
+    return NBODY_OK;
+}
+
+int nbody_frame_publish(nbody_ctx* ctx)
+{
+    if (!ctx) return fail(NBODY_ERR_INVALID, "nbody_frame_publish: null context");
+    if (!ctx->uploaded) return fail(NBODY_ERR_INVALID, "nbody_frame_publish: nothing uploaded");
+    HIP_TRY(hipSetDevice(ctx->device));
+    auto& f = ctx->frames;
+    constexpr int kSlots = nbody_ctx::Frames::kSlots;
+    const size_t nb = sizeof(float) * (size_t)ctx->cfg.num_bodies;
+    if (!f.ready) {
+        HIP_TRY(hipStreamCreateWithFlags(&f.copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < kSlots; ++k) {
+            HIP_TRY(hipMalloc((void**)&f.dev[k], 2 * nb));
+            HIP_TRY(hipHostMalloc((void**)&f.host[k], 2 * nb, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&f.snapped[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&f.landed[k], hipEventDisableTiming));
+        }
+        f.ready = true;
+    }
+    if (f.published - f.acquired >= kSlots)
+        return fail(NBODY_ERR_INVALID, "nbody_frame_publish: %d frames already in flight; call nbody_frame_acquire first", kSlots);
+    const int k = (int)(f.published % kSlots);
+    // The slot's previous frame was acquired, so its host copy has landed and the device snapshot is free.
+    // Snapshot on the compute stream (8 B/body, device to device), host copy on the copy stream: later steps
+    // overwrite posX/posY in place without waiting for PCIe.
+    float* snap = f.dev[k];
+    HIP_TRY(hipMemcpyAsync(snap, ctx->px, nb, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(snap + ctx->cfg.num_bodies, ctx->py, nb, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipEventRecord(f.snapped[k], ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(f.copy_stream, f.snapped[k], 0));
+    HIP_TRY(hipMemcpyAsync(f.host[k], snap, 2 * nb, hipMemcpyDeviceToHost, f.copy_stream));
+    HIP_TRY(hipEventRecord(f.landed[k], f.copy_stream));
+    f.step[k] = ctx->steps_enqueued;
+    ++f.published;
+    return NBODY_OK;
+}
+
+int nbody_frame_acquire(nbody_ctx* ctx, const float** posX, const float** posY, int64_t* step_index)
+{
+    if (!ctx || !posX || !posY) return fail(NBODY_ERR_INVALID, "nbody_frame_acquire: null argument");
+    auto& f = ctx->frames;
+    if (!f.ready || f.acquired >= f.published)
+        return fail(NBODY_ERR_INVALID, "nbody_frame_acquire: no published frame is outstanding");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int k = (int)(f.acquired % nbody_ctx::Frames::kSlots);
+    HIP_TRY(hipEventSynchronize(f.landed[k]));
+    *posX = f.host[k];
+    *posY = f.host[k] + ctx->cfg.num_bodies;
+    if (step_index) *step_index = f.step[k];
+    ++f.acquired;
     return NBODY_OK;
 }
 

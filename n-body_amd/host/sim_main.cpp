@@ -6,7 +6,11 @@
 // circles each frame's positions can be rasterised into a PGM image (--dump-pgm DIR).  Log line format
 // and log.txt append are those of main.cpp:676-700.
 //
-//   nbody_sim [--frames K] [--seed s] [--config path] [--dump-pgm DIR] [--no-log]
+// --async-frames pipelines the two: frame f's positions travel to pinned host memory (nbody_frame_publish /
+// nbody_frame_acquire) and are "rendered" while step f+1 already runs on the GPU; "Physics" then reports the
+// time the host waited for the GPU in that frame.
+//
+//   nbody_sim [--frames K] [--seed s] [--config path] [--dump-pgm DIR] [--async-frames] [--no-log]
 #include "nbody.h"
 #include "config_reader.hpp"
 #include "initial_conditions.hpp"
@@ -20,11 +24,10 @@
 #include <iostream>
 #include <vector>
 
-static void dump_pgm(const std::string& path, const std::vector<float>& x, const std::vector<float>& y, int size,
-                     float half_extent)
+static void dump_pgm(const std::string& path, const float* x, const float* y, size_t count, int size, float half_extent)
 {
     std::vector<unsigned char> img((size_t)size * size, 0);
-    for (size_t i = 0; i < x.size(); ++i) {
+    for (size_t i = 0; i < count; ++i) {
         const int u = (int)((x[i] / half_extent * 0.5f + 0.5f) * size);
         const int v = (int)((y[i] / half_extent * 0.5f + 0.5f) * size);
         if (u >= 0 && u < size && v >= 0 && v < size) {
@@ -42,7 +45,7 @@ int main(int argc, char** argv)
     int frames = 100;
     uint32_t seed = 12345u;
     std::string config_name = "config.json", dump_dir;
-    bool write_log = true;
+    bool write_log = true, async_frames = false;
     for (int i = 1; i < argc; ++i) {
         auto next = [&](const char* flag) -> const char* {
             if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", flag); std::exit(2); }
@@ -53,6 +56,7 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--config")) config_name = next("--config");
         else if (!std::strcmp(argv[i], "--dump-pgm")) dump_dir = next("--dump-pgm");
         else if (!std::strcmp(argv[i], "--no-log")) write_log = false;
+        else if (!std::strcmp(argv[i], "--async-frames")) async_frames = true;
         else { std::fprintf(stderr, "unknown flag %s\n", argv[i]); return 2; }
     }
 
@@ -86,21 +90,42 @@ int main(int argc, char** argv)
     double elapsed = 0.0;
     for (int f = 0; f < frames; ++f) {
         const auto frameStart = Clock::now();
-        const auto physicsStart = Clock::now();
-        if (nbody_step(ctx, 1) != NBODY_OK || nbody_sync(ctx) != NBODY_OK) {
-            std::fprintf(stderr, "nbody_step: %s\n", nbody_last_error());
-            return 1;
-        }
-        const auto physicsEnd = Clock::now();
-        // "rendering pass": the renderer needs positions only (main.cpp:650-653)
-        if (nbody_download(ctx, data.posX.data(), data.posY.data(), nullptr, nullptr) != NBODY_OK) {
-            std::fprintf(stderr, "nbody_download: %s\n", nbody_last_error());
-            return 1;
+        auto physicsStart = Clock::now();
+        auto physicsEnd = physicsStart;
+        const float *fx = nullptr, *fy = nullptr;
+        int shown = f;                               // which step's positions this frame draws
+        if (!async_frames) {
+            if (nbody_step(ctx, 1) != NBODY_OK || nbody_sync(ctx) != NBODY_OK) {
+                std::fprintf(stderr, "nbody_step: %s\n", nbody_last_error());
+                return 1;
+            }
+            physicsEnd = Clock::now();
+            // "rendering pass": the renderer needs positions only (main.cpp:650-653)
+            if (nbody_download(ctx, data.posX.data(), data.posY.data(), nullptr, nullptr) != NBODY_OK) {
+                std::fprintf(stderr, "nbody_download: %s\n", nbody_last_error());
+                return 1;
+            }
+            fx = data.posX.data();
+            fy = data.posY.data();
+        } else {
+            // enqueue step f and its snapshot, then draw frame f-1 (frame 0 is drawn together with frame 1's step)
+            if (nbody_step(ctx, 1) != NBODY_OK || nbody_frame_publish(ctx) != NBODY_OK) {
+                std::fprintf(stderr, "nbody_step/frame_publish: %s\n", nbody_last_error());
+                return 1;
+            }
+            if (f == 0 && frames > 1) continue;
+            int64_t step_index = 0;
+            if (nbody_frame_acquire(ctx, &fx, &fy, &step_index) != NBODY_OK) {
+                std::fprintf(stderr, "nbody_frame_acquire: %s\n", nbody_last_error());
+                return 1;
+            }
+            physicsEnd = Clock::now();
+            shown = (int)step_index - 1;
         }
         if (!dump_dir.empty()) {
             char name[64];
-            std::snprintf(name, sizeof(name), "/frame_%05d.pgm", f);
-            dump_pgm(dump_dir + name, data.posX, data.posY, std::min(sc.windowSize, 2048), sc.windowSize * 0.5f);
+            std::snprintf(name, sizeof(name), "/frame_%05d.pgm", shown);
+            dump_pgm(dump_dir + name, fx, fy, (size_t)n, std::min(sc.windowSize, 2048), sc.windowSize * 0.5f);
         }
         const auto frameEnd = Clock::now();
         const double frameMs = std::chrono::duration<double, std::milli>(frameEnd - frameStart).count();
@@ -117,6 +142,20 @@ int main(int argc, char** argv)
             elapsed = 0.0;
         }
     }
+    if (async_frames && frames > 1) {              // the last frame is still in flight
+        const float *fx = nullptr, *fy = nullptr;
+        int64_t step_index = 0;
+        if (nbody_frame_acquire(ctx, &fx, &fy, &step_index) != NBODY_OK) {
+            std::fprintf(stderr, "nbody_frame_acquire: %s\n", nbody_last_error());
+            return 1;
+        }
+        if (!dump_dir.empty()) {
+            char name[64];
+            std::snprintf(name, sizeof(name), "/frame_%05d.pgm", (int)step_index - 1);
+            dump_pgm(dump_dir + name, fx, fy, (size_t)n, std::min(sc.windowSize, 2048), sc.windowSize * 0.5f);
+        }
+    }
+    if (nbody_sync(ctx) != NBODY_OK) { std::fprintf(stderr, "nbody_sync: %s\n", nbody_last_error()); return 1; }
     nbody_destroy(ctx);
     return 0;
 }

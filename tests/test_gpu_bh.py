@@ -215,3 +215,44 @@ def test_clustered_plummer_theta05(nb, O):
     idx = np.arange(0, n, 257, dtype=np.int32)
     nx, ny = O.naive_accel_f64_subset(b, idx)
     assert np.median(rel_err(ax[idx], ay[idx], nx, ny)) < 0.01
+
+
+@pytest.mark.parametrize("n,scale", [(2048, 1.5), (10000, 3.0), (1000, 0.01)])
+def test_adaptive_root_box_equals_oracle_with_that_box(nb, O, n, scale):
+    """Opt-in nbody_config.adaptive_box (no reference counterpart): the root box is [-h,h]^2 with
+    h = max(|x|,|y|) over all bodies, recomputed on the GPU every build.  The result must be what the reference's
+    tree gives when it is handed that h as `spread` (benchmark.cpp:169) — bit for bit, against the oracle."""
+    b = O.init_disc(n, seed=31)
+    b.posX *= scale; b.posY *= scale
+    h = float(max(np.abs(b.posX).max(), np.abs(b.posY).max()))
+    ax, ay, _, tree, cnt = gpu_bh(nb, b, want_tree=True, adaptive_box=True, spread=400.0)
+    assert tree[0]["brX"] == np.float32(h) and tree[0]["tlX"] == -np.float32(h)
+    ot = O.Tree(n).build(b, h)
+    assert len(tree) == ot.nodes_used
+    assert np.array_equal(canonical(tree), canonical(ot.pool()))
+    leaves = tree[tree["children"][:, 0] == -1]
+    assert (leaves["bodyIndex"] >= 0).sum() >= n                       # nobody is dropped (ghosts may add leaves)
+    ox, oy, ocnt = ot.accel(b, 1.0)
+    assert cnt == ocnt and np.array_equal(ax, ox.astype(np.float32)) and np.array_equal(ay, oy.astype(np.float32))
+
+
+def test_adaptive_root_box_follows_the_bodies_while_stepping(nb, O):
+    """Bodies on escape trajectories leave the fixed box and stop exerting force (benchmark.cpp:83-85); with the
+    adaptive box the tree keeps all of them at every step."""
+    n = 4096
+    b = O.init_disc(n, seed=8)
+    b.velX *= 40.0; b.velY *= 40.0                   # unbound: the disc flies apart
+    with nb.NBodySim(n, dt=0.05, useBarnesHut=True, adaptive_box=True) as sim:
+        sim.upload(*b.arrays())
+        sim.step(30).sync()
+        st = sim.download()
+        tree = sim.bh_tree()                          # tree of the positions BEFORE the last Euler update
+    assert (np.abs(st["posX"]) > 400).sum() > n // 10
+    leaves = tree[tree["children"][:, 0] == -1]
+    assert (leaves["bodyIndex"] >= 0).sum() >= n
+    assert np.isclose(tree[0]["mass"], b.m.sum(), rtol=1e-5)
+    with nb.NBodySim(n, dt=0.05, useBarnesHut=True) as sim:           # the reference's fixed box loses them
+        sim.upload(*b.arrays())
+        sim.step(30).sync()
+        fixed = sim.bh_tree()
+    assert fixed[0]["mass"] < 0.95 * b.m.sum()

@@ -57,3 +57,23 @@ def test_sim_driver_reads_config_and_dumps_frames(tmp_path):
     assert raw.startswith(b"P5\n256 256\n255\n")
     img = np.frombuffer(raw[len(b"P5\n256 256\n255\n"):], np.uint8)
     assert img.size == 256 * 256 and (img > 0).sum() > 500   # bodies were rasterised from the downloaded posX/posY
+
+
+def test_sim_driver_async_frames_equal_synchronous_frames(tmp_path):
+    """--async-frames (nbody_frame_publish/acquire: frame f is drawn while step f+1 runs) must draw exactly the
+    frames the synchronous download path draws."""
+    (tmp_path / "config.json").write_text(
+        '{ "simulation": { "useBarnesHut": true, "useParallel": true, "numBodies": 8192, "spread": 400.0, "mass": 1000.0,'
+        ' "theta": 1.0, "dt": 0.05 }, "display": { "windowSize": 200, "windowTitle": "t" } }')
+    out = {}
+    for mode in ("sync", "async"):
+        d = tmp_path / mode
+        d.mkdir()
+        cmd = [os.path.join(BIN, "nbody_sim"), "--frames", "5", "--dump-pgm", str(d), "--no-log"]
+        r = run(cmd + (["--async-frames"] if mode == "async" else []), tmp_path)
+        assert r.returncode == 0, r.stderr
+        assert "Mode: BarnesHut" in r.stdout
+        out[mode] = [p.read_bytes() for p in sorted(d.glob("frame_*.pgm"))]
+    assert len(out["sync"]) == len(out["async"]) == 5
+    assert out["sync"] == out["async"]
+    assert out["sync"][0] != out["sync"][-1]
