@@ -59,6 +59,24 @@ def cpu_baseline(budget_s=12.0):
                 sample="oracle/nbody_oracle.c f32 restatement, N=16384, one force pass")
 
 
+def cpu_baseline_bh(n, theta):
+    """The reference's own Barnes-Hut step (oracle/_ref) on this host's threads: same bodies, steps 1-3."""
+    O = entry.load_oracle()
+    import ctypes
+    try:
+        cores = ctypes.CDLL("libgomp.so.1").omp_get_max_threads()
+    except OSError:
+        cores = os.cpu_count()
+    if not O.ref_available():
+        return None
+    b = O.init_disc(n, seed=12345)
+    r = O.ref_run(n, use_barnes_hut=1, nsteps=3, bodies=b, theta=theta)
+    med = float(np.median(r["step_ms"]))
+    return dict(value=med, unit="ms/step", cores=int(cores), kind="reference",
+                sample=f"reference benchmark.cpp Barnes-Hut loop (serial build + OpenMP walk), N={n}, theta={theta}, "
+                       f"median of steps 1-3")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +87,8 @@ def main():
     ap.add_argument("--workload", choices=["naive", "bh"], default="naive",
                     help="naive = the BASELINE.json metric (default); bh = Barnes-Hut ms/step (BASELINE configs 4-5)")
     ap.add_argument("--theta", type=float, default=1.0)
+    ap.add_argument("--bh-fast-math", action="store_true",
+                    help="bh workload: 1-ulp hardware sqrt/rcp in the walk (same votes, terms differ by a few ulp)")
     args = ap.parse_args()
     if os.environ.get("NBODY_DEBUG"):
         import faulthandler
@@ -104,7 +124,8 @@ def main():
     bodies = O.init_disc(n, seed=12345)      # benchmark.cpp:317-339, seed fixed
 
     bh = args.workload == "bh"
-    sim = ShardedSim(pkg, n, rank, world, device=local_rank, dt=0.05, dist=dist, useBarnesHut=bh, theta=args.theta)
+    sim = ShardedSim(pkg, n, rank, world, device=local_rank, dt=0.05, dist=dist, useBarnesHut=bh, theta=args.theta,
+                     bh_fast_math=bh and args.bh_fast_math)
     sim.upload(*bodies.arrays())
     my_targets = owned_targets(n, sim.spans, rank)
 
@@ -115,9 +136,15 @@ def main():
 
     sim.step(args.warmup)
     barrier()
+    if bh:
+        # The reference's disc is unbound (velocity factor 0.3): within ~10 steps most bodies have left the fixed
+        # root box and the walk shrinks (SURVEY.md §6.2, §8d "time steps 1-5 only").  Warm-up therefore runs on the
+        # same context (graph captured, clocks up) and the INITIAL state is uploaded again before the timed steps.
+        sim.upload(*bodies.arrays())
+        barrier()
     # naive: per-kernel hipEvent timing stays on inside the timed region (2 launches per step, ~180 ms each).
     # Barnes-Hut: the timed region runs the captured hipGraph (no event pairs inside a capture); the per-kernel
-    # figures come from a short eager pass AFTER it.
+    # figures come from one eager step (step 1 of the same state) AFTER it.
     sim.sim.profile(not bh).profile_reset()
     barrier()
     t0 = time.perf_counter()
@@ -125,8 +152,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if bh:
+        sim.upload(*bodies.arrays())
         sim.sim.profile(True).profile_reset()
-        sim.step(3)
+        sim.step(1)                    # per-kernel times and the visit counters both describe step 1
         barrier()
     force_ms, force_launches = sim.sim.profile_read(0)
     integ_ms, integ_launches = sim.sim.profile_read(1)
@@ -138,21 +166,27 @@ def main():
     if rank == 0 and bh:
         build_ms, build_launches = sim.sim.profile_read(2)
         cnt = sim.sim.bh_counters()
+        walk_ms = force_ms / max(1, force_launches)
+        # algorithmic bytes of one walk launch: one 24-B node record (float4 + int2) per group-visit
+        walk_gbs = 24.0 * cnt["visits"] / (walk_ms * 1e-3) / 1e9
         line = {
             "metric": f"ms/step, Barnes-Hut theta={args.theta} step", "value": elapsed * 1e3 / args.steps, "unit": "ms/step",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Barnes-Hut step (tree build + COM + group-of-8 walk + Euler), N={n}, theta={args.theta}, "
-                                   f"seeded disc (benchmark.cpp:317-339, seed 12345); timed steps follow {args.warmup} warm-up "
-                                   f"steps (bodies leave the fixed root box over time, SURVEY.md §6.2)",
-                       "num_bodies": n, "parallelism": f"tree replicated, walk i-sharded x{world}"},
-            "roofline": {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
-                         "kernel": "bh_walk_kernel", "kernel_ms": force_ms / max(1, force_launches),
+                                   f"seeded disc (benchmark.cpp:317-339, seed 12345); timed: steps 1-{args.steps} of that state "
+                                   f"(warm-up ran on the same context, then the initial state was uploaded again)",
+                       "num_bodies": n, "parallelism": f"tree replicated, walk i-sharded x{world}",
+                       "arithmetic": "hardware sqrt/rcp, exact vote" if args.bh_fast_math else "IEEE (bit-identical to the oracle)"},
+            "roofline": {"bound": "hbm", "achieved": walk_gbs, "peak": 8000.0, "unit": "GB/s", "frac": walk_gbs / 8000.0,
+                         "traffic": None, "kernel": "bh_walk_kernel", "kernel_ms": walk_ms,
                          "build_ms": build_ms / max(1, build_launches), "launches": int(force_launches),
-                         "node_visits_last_step": int(cnt["visits"]), "accepted_nodes_last_step": int(cnt["accepts"]),
-                         "note": "latency-bound pointer chase: 24 B per node visit, mostly L2-resident; no flop convention "
-                                 "(SURVEY.md §8d)"},
+                         "node_visits_step1": int(cnt["visits"]), "accepted_nodes_step1": int(cnt["accepts"]),
+                         "note": "dependent-load tree walk: 24 B per group-visit (rank 0's launch), mostly L2-resident, "
+                                 "so the HBM fraction is a floor, not a target; no flop convention (SURVEY.md §8d)"},
         }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_bh(n, args.theta)
         print(json.dumps(line), flush=True)
     elif rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps

@@ -63,7 +63,11 @@ typedef struct nbody_config {
                                 outside it exert no force (benchmark.cpp:83-85,169).  1 (opt-in, no reference
                                 counterpart): every step the root box is [-h,h]^2 with
                                 h = max_i max(|x_i|,|y_i|) over all finite positions, so no body escapes the tree */
-    int32_t reserved[3];
+    int32_t bh_fast_math;    /* Barnes-Hut only.  0 (default): IEEE sqrt/divisions, bit-identical to the plain-C oracle.
+                                1: the GPU's 1-ulp sqrt/reciprocal in the walk; the accept/open VOTE is still decided
+                                exactly (borderline ratios are re-evaluated in IEEE arithmetic), so the same nodes
+                                are visited and accepted and only the summed terms differ, by a few ulp each      */
+    int32_t reserved[2];
 } nbody_config;
 
 /* Defaults = benchmark.cpp:300-306 (BH on, n=10000, spread=400, mass=1000, theta=1, dt=0.05). */

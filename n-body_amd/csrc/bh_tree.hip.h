@@ -420,6 +420,12 @@ struct BhWalkArgs {
     float theta;
 };
 
+// kFast = false: IEEE sqrt and divisions everywhere; every lane reproduces oracle_bh_accel() bit for bit.
+// kFast = true (nbody_config.bh_fast_math): the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32.  The VOTE stays the
+// oracle's: the approximate ratio decides only when it is further than 4e-6 (relative; > 10x its error bound of
+// ~3.5 ulp) from theta, otherwise the wave redoes that node with the IEEE expressions.  So the visit pattern
+// and the counters are identical in both modes and only the accepted terms differ, by a few ulp each.
+template <bool kFast>
 __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
 {
 #pragma clang fp contract(off)   // every fma below is explicit: lanes reproduce oracle_bh_accel() bit for bit
@@ -435,6 +441,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     const float xi = w.px[ic], yi = w.py[ic], ri = w.radius[ic];
     const int grp_shift = (tid & 63) & ~7;                      // first lane of this group inside the wave
     const float eps = 1e-6f, soft2 = 0.001f * 0.001f;
+    const float vote_margin = 4e-6f * w.theta;
     float ax = 0.0f, ay = 0.0f;
     unsigned visits = 0, accepts = 0;
 
@@ -453,16 +460,33 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
             bool open = false;
             if (a.z != 0.0f) {                                  // benchmark.cpp:248
                 const float dx = a.x - xi, dy = a.y - yi;       // :254-255
-                const float d = __builtin_sqrtf(__builtin_fmaf(dx, dx, dy * dy));   // :256-257
-                const bool far = (a.w / (d + eps)) < w.theta;                       // :259-262
+                const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+                float d, inv;
+                bool far;
+                if constexpr (kFast) {
+                    d = __builtin_amdgcn_sqrtf(d2);
+                    inv = __builtin_amdgcn_rcpf(d + eps);
+                    const float q = a.w * inv;
+                    far = q < w.theta;
+                    if (__any(__builtin_fabsf(q - w.theta) <= vote_margin))          // rare: ~1e-4 of the waves' visits
+                        far = (a.w / (__builtin_sqrtf(d2) + eps)) < w.theta;
+                } else {
+                    d = __builtin_sqrtf(d2);                                         // :256-257
+                    far = (a.w / (d + eps)) < w.theta;                               // :259-262
+                }
                 const unsigned long long fm = __ballot(far || !live);
                 const bool all_far = ((fm >> grp_shift) & 0xFFull) == 0xFFull;
                 if (b.x < 0 || all_far) {                       // :266 leaf or every lane far
                     ++accepts;
                     // computeForce_kernel, benchmark.cpp:188-225
                     const float sd = __builtin_fmaxf(d, ri);    // clamp radius is the TARGET's only (:201-202)
-                    const float f = a.z / __builtin_fmaf(sd, sd, soft2);   // :203-209
-                    const float inv = 1.0f / (d + eps);         // :212-213
+                    float f;
+                    if constexpr (kFast) {
+                        f = a.z * __builtin_amdgcn_rcpf(__builtin_fmaf(sd, sd, soft2));
+                    } else {
+                        f = a.z / __builtin_fmaf(sd, sd, soft2);   // :203-209
+                        inv = 1.0f / (d + eps);                    // :212-213
+                    }
                     const bool self = b.y == i;                 // :197-198
                     ax = ax + (self ? 0.0f : (dx * inv) * f);
                     ay = ay + (self ? 0.0f : (dy * inv) * f);

@@ -260,7 +260,9 @@ int enqueue_bh_walk(nbody_ctx* ctx)
     EventPair* ep;
     int rc = profile_begin(ctx, 0, &ep);
     if (rc) return rc;
-    bh_walk_kernel<<<dim3((nt + kBhBlock - 1) / kBhBlock), dim3(kBhBlock), 0, ctx->stream>>>(w);
+    const dim3 grid((nt + kBhBlock - 1) / kBhBlock), blk(kBhBlock);
+    if (ctx->cfg.bh_fast_math) bh_walk_kernel<true><<<grid, blk, 0, ctx->stream>>>(w);
+    else                       bh_walk_kernel<false><<<grid, blk, 0, ctx->stream>>>(w);
     HIP_TRY(hipGetLastError());
     return profile_end(ctx, 0, ep);
 }
@@ -506,12 +508,12 @@ int nbody_upload(nbody_ctx* ctx, const float* m, const float* posX, const float*
     ctx->out_scale = variant == kScaled ? m[0] / (r0 * r0) : (variant == kUniform ? m[0] : 1.0f);
     plan_force(ctx);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (ctx->step_graph) {                       // buffers may move below: re-capture on the next step
-        (void)hipGraphExecDestroy(ctx->step_graph);
-        ctx->step_graph = nullptr;
-    }
     const int rows = ctx->cfg.use_barnes_hut ? 1 : ctx->slices;
     if (rows > ctx->partial_rows) {
+        if (ctx->step_graph) {                   // the partial buffers move: re-capture on the next step
+            (void)hipGraphExecDestroy(ctx->step_graph);
+            ctx->step_graph = nullptr;
+        }
         if (ctx->pax) HIP_TRY(hipFree(ctx->pax));
         if (ctx->pay) HIP_TRY(hipFree(ctx->pay));
         ctx->pax = ctx->pay = nullptr;

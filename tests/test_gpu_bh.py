@@ -256,3 +256,31 @@ def test_adaptive_root_box_follows_the_bodies_while_stepping(nb, O):
         sim.step(30).sync()
         fixed = sim.bh_tree()
     assert fixed[0]["mass"] < 0.95 * b.m.sum()
+
+
+@pytest.mark.parametrize("name", ["bh_n1003_theta1", "bh_n10000_theta1", "bh_n10000_theta05"])
+def test_fast_math_walk_takes_the_same_votes(nb, O, name):
+    """nbody_config.bh_fast_math: hardware sqrt/rcp (1 ulp) in the walk.  The accept/open decisions must still be the
+    oracle's (visit and accept counters EQUAL); the accelerations may differ by the rounding of the summed terms
+    only — gate: median 2e-7, max 2e-5 of |a| per body (terms partly cancel in the sum; the north-star tolerance
+    is 1e-4)."""
+    g, b = load_golden(O, name)
+    theta = float(g["theta"])
+    ax, ay, _, _, cnt = gpu_bh(nb, b, theta=theta, bh_fast_math=True)
+    ot = O.Tree(b.n).build(b, 400.0)
+    ox, oy, ocnt = ot.accel(b, theta)
+    assert cnt == ocnt
+    lim = b.n - b.n % 8
+    e = rel_err(ax[:lim], ay[:lim], ox[:lim], oy[:lim])
+    assert np.median(e) <= 2e-7 and e.max() <= 2e-5, (np.median(e), e.max())
+    assert not (np.array_equal(ax, ox.astype(np.float32)) and np.array_equal(ay, oy.astype(np.float32)))  # it IS another path
+
+
+def test_fast_math_walk_n1m_same_counters(nb, O):
+    n = 1_000_000
+    b = O.init_disc(n, seed=12345)
+    ax, ay, _, _, cnt = gpu_bh(nb, b, bh_fast_math=True)
+    ex, ey, _, _, ecnt = gpu_bh(nb, b)
+    assert cnt == ecnt                                # 1.08e8 group-visits: not one vote differs
+    e = rel_err(ax, ay, ex, ey)
+    assert np.median(e) <= 2e-7 and e.max() <= 5e-5, (np.median(e), e.max())
