@@ -222,10 +222,16 @@ class NBodySim:
         _check(lib().nbody_get_info(self._h, C.byref(v), C.byref(s), C.byref(b)))
         return dict(force_variant=v.value, j_slices=s.value, blocks=b.value)
 
-    def bh_tree(self):
+    def bh_tree(self, max_nodes=None):
+        """Node pool of the last build as 48-byte QuadNode records (benchmark.cpp:52-60); node 0 is the root.
+        max_nodes limits the copy (a 2^24-body tree has ~4.6e7 nodes = 2.2 GB); len() of the result is then the
+        number copied, and .total the number of nodes in the tree."""
         n = lib().nbody_bh_tree_nodes(self._h, None, 0)
         if n < 0:
             raise NBodyError(int(n), lib().nbody_last_error().decode())
+        self.bh_nodes_total = int(n)
+        if max_nodes is not None:
+            n = min(n, int(max_nodes))
         from numpy import dtype
         node = dtype([("mass", "f4"), ("comX", "f4"), ("comY", "f4"), ("tlX", "f4"), ("tlY", "f4"),
                       ("brX", "f4"), ("brY", "f4"), ("bodyIndex", "i4"), ("children", "i4", (4,))])

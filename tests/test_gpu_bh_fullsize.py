@@ -1,0 +1,54 @@
+"""BASELINE config 5 at its full size on one GPU: Barnes-Hut theta = 0.5, N = 2^24, clustered (Plummer-like) input,
+one rank's share of an 8-way run.  The oracle cannot build a 16M-body tree in seconds, so the checks are the
+size-independent ones: conservation in the tree (root mass / centre of mass), shard invariance, and the
+approximation error against the float64 direct sum on sampled targets (oracle_naive_accel_f64_subset).
+The input generator is this repository's (oracle.init_plummer; the reference has none)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config5_plummer_16m_one_rank_of_eight(nb, O):
+    n, theta, world = 1 << 24, 0.5, 8
+    b = O.init_plummer(n, scale=50.0, seed=12345)
+    inside = (np.abs(b.posX) <= 400) & (np.abs(b.posY) <= 400)
+    assert 0.9 < inside.mean() < 1.0                                  # some bodies ARE outside the fixed box
+    span = nb.shard_range(n, world, 3)
+    with nb.NBodySim(n, theta=theta, useBarnesHut=True, shard=span) as sim:
+        sim.upload(*b.arrays())
+        sim.compute_accel().sync()
+        ax, ay = sim.accel()
+        root = sim.bh_tree(max_nodes=1)[0]
+        nodes = sim.bh_nodes_total
+        cnt = sim.bh_counters()
+    # tree-wide conservation (benchmark.cpp:122-141 applied bottom-up over ~4.6e7 nodes)
+    m_in = b.m[inside].astype(np.float64)
+    # Bodies exactly ON a split line enter both children (inclusive bounds, benchmark.cpp:83-85) and count twice in
+    # the reference's tree; in this dense cluster (cells down to 800/2^20 wide against a float spacing of 4e-6)
+    # that is a few thousand of the 1.66e7 bodies, so the root mass exceeds the plain sum by that much.
+    excess = float(root["mass"]) / m_in.sum() - 1.0
+    assert -2e-6 <= excess <= 1e-3, excess
+    assert abs(root["comX"] - np.average(b.posX[inside].astype(np.float64), weights=m_in)) < 1e-2
+    assert abs(root["comY"] - np.average(b.posY[inside].astype(np.float64), weights=m_in)) < 1e-2
+    assert (root["tlX"], root["tlY"], root["brX"], root["brY"]) == (-400.0, -400.0, 400.0, 400.0)
+    assert int(inside.sum()) < nodes <= 8 * n + 257 and (nodes - 1) % 4 == 0
+    # only the owned targets were walked, every one of them
+    own = np.zeros(n, bool); own[span[0]:span[0] + span[1]] = True
+    assert np.all(ax[~own] == 0) and np.all(ay[~own] == 0)
+    assert np.all(np.isfinite(ax)) and np.all(np.hypot(ax, ay)[own] > 0)
+    assert cnt["visits"] > cnt["accepts"] > span[1] // 8
+    # approximation error vs the f64 direct sum over all 2^24 sources, 96 sampled targets of the shard
+    idx = np.arange(span[0], span[0] + span[1], span[1] // 96, dtype=np.int32)[:96]
+    nx, ny = O.naive_accel_f64_subset(b, idx)
+    err = np.hypot(ax[idx] - nx, ay[idx] - ny) / np.hypot(nx, ny)
+    assert np.median(err) <= 0.02 and np.percentile(err, 90) <= 0.06, (np.median(err), np.percentile(err, 90), err.max())
+    # shard invariance at full size: another decomposition gives the same bits for the same targets
+    half = nb.shard_range(n, 16, 6)                                    # = first half of rank 3 of 8
+    assert half[0] == span[0]
+    with nb.NBodySim(n, theta=theta, useBarnesHut=True, shard=half, bh_fast_math=False) as sim:
+        sim.upload(*b.arrays())
+        sim.compute_accel().sync()
+        hx, hy = sim.accel()
+    sl = slice(half[0], half[0] + half[1])
+    assert np.array_equal(hx[sl], ax[sl]) and np.array_equal(hy[sl], ay[sl])
