@@ -64,7 +64,6 @@ struct BhCounters {          // device-resident scalars of one build/walk
 struct BhTree {
     float4* __restrict__ A;
     int2* __restrict__ B;
-    float4* __restrict__ box;            // {tlX, tlY, brX, brY} (read-back / child boxes)
     uint8_t* __restrict__ depth;         // per internal cell
     int* __restrict__ self;              // per internal cell: its node index
     int cap_internal;
@@ -80,7 +79,8 @@ __device__ __forceinline__ int bh_lcp_levels(uint64_t a, uint64_t b)
 // 1. path keys ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBhBlock) void bh_keys_kernel(const float* __restrict__ px, const float* __restrict__ py,
                                                            int n, const BhCounters* __restrict__ ctr,
-                                                           uint64_t* __restrict__ keys, int* __restrict__ vals)
+                                                           uint64_t* __restrict__ keys, int* __restrict__ vals,
+                                                           uint16_t* __restrict__ tie)
 {
     const int i = blockIdx.x * kBhBlock + threadIdx.x;
     if (i >= n) return;
@@ -88,6 +88,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_keys_kernel(const float* __restri
     const float x = px[i], y = py[i];
     float tlx = -spread, tly = -spread, brx = spread, bry = spread;
     uint64_t key;
+    int tx = kBhLevels, ty = kBhLevels;                    // first level at which x (y) sits ON the split line
     if (x < tlx || x > brx || y < tly || y > bry) {         // benchmark.cpp:83-85
         key = kBhInvalidKey | (uint64_t)(uint32_t)i;       // keep invalid keys distinct and ordered
     } else {
@@ -95,6 +96,8 @@ __global__ __launch_bounds__(kBhBlock) void bh_keys_kernel(const float* __restri
 #pragma unroll 1
         for (int l = 0; l < kBhLevels; ++l) {
             const float mx = (tlx + brx) / 2.0f, my = (tly + bry) / 2.0f;    // benchmark.cpp:98-99
+            tx = (x == mx && tx == kBhLevels) ? l : tx;
+            ty = (y == my && ty == kBhLevels) ? l : ty;
             const int qx = x > mx, qy = y > my;            // on the line -> lower child
             key = (key << 2) | (uint64_t)(qy * 2 + qx);    // TL, TR, BL, BR (benchmark.cpp:105-108)
             tlx = qx ? mx : tlx; brx = qx ? brx : mx;
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_keys_kernel(const float* __restri
     }
     keys[i] = key;
     vals[i] = i;
+    tie[i] = (uint16_t)(tx | (ty << 8));
 }
 
 // number of valid (in-box) bodies = first sorted index with the invalid bit set
@@ -179,21 +183,21 @@ __device__ __forceinline__ uint64_t bh_descend(float x, float y, float spread, i
 // 2b. second instances.  Runs on the sorted primaries; leaf depth of body i = 1 + max(lcp with its neighbours).
 __global__ __launch_bounds__(kBhBlock) void bh_ties_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
                                                            const float* __restrict__ px, const float* __restrict__ py,
-                                                           BhCounters* __restrict__ ctr,
+                                                           const uint16_t* __restrict__ tie, BhCounters* __restrict__ ctr,
                                                            uint64_t* __restrict__ gkeys, int* __restrict__ gvals, int gcap)
 {
     const int i = blockIdx.x * kBhBlock + threadIdx.x;
     const int M = ctr->valid;
     if (i >= M) return;
+    const int b = vals[i];
+    const int tx = tie[b] & 0xFF, ty = tie[b] >> 8;           // recorded by bh_keys_kernel
+    if (tx == kBhLevels && ty == kBhLevels) return;           // all but a few hundred per million
     const float spread = ctr->root_half;
     const uint64_t k = keys[i];
     const int lp = i > 0 ? bh_lcp_levels(keys[i - 1], k) : -1;
     const int ln = i + 1 < M ? bh_lcp_levels(k, keys[i + 1]) : -1;
     const int leaf_depth = 1 + (lp > ln ? lp : ln);           // 0 when the body is alone in the tree
-    const int b = vals[i];
     const float x = px[b], y = py[b];
-    int tx, ty;
-    (void)bh_descend(x, y, spread, -1, -1, &tx, &ty);
     const bool ax_on = tx < leaf_depth, ay_on = ty < leaf_depth;   // the cell where the tie happens is internal
     if (!ax_on && !ay_on) return;
     uint64_t out[3];
@@ -266,9 +270,34 @@ __device__ __forceinline__ int bh_lower_bound(const uint64_t* __restrict__ keys,
     return lo;
 }
 
+// first index in [lo, hi) whose key is >= v, galloping from lo (the answer is usually a few bodies away)
+__device__ __forceinline__ int bh_gallop_lower_bound(const uint64_t* __restrict__ keys, int lo, int hi, uint64_t v)
+{
+    int a = lo, step = 1;
+    while (a + step <= hi && keys[a + step - 1] < v) { a += step; step <<= 1; }
+    const int e = a + step < hi ? a + step : hi;
+    return bh_lower_bound(keys, a, e, v);
+}
+
 // 4. nodes ---------------------------------------------------------------------------------------------------
+// 4a. owner of every internal cell: sorted instance i owns the cnt[i] cells base[i].. (the cells whose first body
+// it is), at depths lcp(i-1,i)+1...  Scattering the owner once replaces a 24-step binary search per cell.
+__global__ __launch_bounds__(kBhBlock) void bh_owner_kernel(const int* __restrict__ cnt, const int* __restrict__ base, int n,
+                                                            const BhCounters* __restrict__ ctr, int* __restrict__ owner,
+                                                            int cap_internal)
+{
+    const int i = blockIdx.x * kBhBlock + threadIdx.x;
+    if (i >= n || i >= ctr->valid) return;
+    const int ci = cnt[i], c0 = base[i];
+    for (int k = 0; k < ci; ++k)
+        if (c0 + k < cap_internal) owner[c0 + k] = i;
+}
+
+// 4b. one thread per internal cell: box, body range (galloping from the owner: the range of a typical cell is a
+// few bodies long), the four children.
 __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
-                                                            const int* __restrict__ cnt, const int* __restrict__ base, int n,
+                                                            const int* __restrict__ cnt, const int* __restrict__ base,
+                                                            const int* __restrict__ owner, int n,
                                                             const float* __restrict__ m, const float* __restrict__ px,
                                                             const float* __restrict__ py, BhTree t,
                                                             BhCounters* __restrict__ ctr)
@@ -284,18 +313,11 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* __re
             const int b = M == 1 ? vals[0] : -1;
             t.A[0] = make_float4(b >= 0 ? px[b] : 0.0f, b >= 0 ? py[b] : 0.0f, b >= 0 ? m[b] : 0.0f, 2.0f * spread);
             t.B[0] = make_int2(-1, b);
-            t.box[0] = make_float4(-spread, -spread, spread, spread);
         }
     }
     if (c >= I || c >= t.cap_internal) return;
 
-    // owner body i of cell c: last i with base[i] <= c
-    int lo = 0, hi = M;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (base[mid] <= c) lo = mid + 1; else hi = mid;
-    }
-    const int i = lo - 1;
+    const int i = owner[c];
     const uint64_t ki = keys[i];
     const int lp = i > 0 ? bh_lcp_levels(keys[i - 1], ki) : -1;
     const int d = lp + 1 + (c - base[i]);                      // depth of this cell, 0..30
@@ -311,7 +333,6 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* __re
         if (q & 2) tly = my; else bry = my;
     }
     if (c == 0) {
-        t.box[0] = make_float4(tlx, tly, brx, bry);
         t.A[0] = make_float4(0.0f, 0.0f, 0.0f, brx - tlx);
         t.B[0] = make_int2(1, -1);
         t.self[0] = 0;
@@ -319,21 +340,19 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* __re
     t.depth[c] = (uint8_t)d;
 
     // body range [i, e) of the cell and its quadrant boundaries
-    const int e = d ? bh_lower_bound(keys, i + 1, M, (prefix + 1) << shift) : M;
+    const int e = d ? bh_gallop_lower_bound(keys, i + 1, M, (prefix + 1) << shift) : M;
     const int cshift = shift - 2;
     int s[5];
     s[0] = i;
     s[4] = e;
 #pragma unroll
-    for (int q = 1; q < 4; ++q) s[q] = bh_lower_bound(keys, s[q - 1], e, ((prefix << 2) | (uint64_t)q) << cshift);
+    for (int q = 1; q < 4; ++q) s[q] = bh_gallop_lower_bound(keys, s[q - 1], e, ((prefix << 2) | (uint64_t)q) << cshift);
 
-    const float mx = (tlx + brx) / 2.0f, my = (tly + bry) / 2.0f;
+    const float mx = (tlx + brx) / 2.0f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int node = 1 + 4 * c + q;
         const float ctlx = (q & 1) ? mx : tlx, cbrx = (q & 1) ? brx : mx;
-        const float ctly = (q & 2) ? my : tly, cbry = (q & 2) ? bry : my;
-        t.box[node] = make_float4(ctlx, ctly, cbrx, cbry);
         const float width = cbrx - ctlx;                       // benchmark.cpp:251
         const int cntq = s[q + 1] - s[q];
         int child_base = -1, body = -1;
@@ -357,12 +376,34 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* __re
     }
 }
 
-// 5. centre of mass, one launch per depth (deepest first) ---------------------------------------------------
-__global__ __launch_bounds__(kBhBlock) void bh_com_kernel(BhTree t, const BhCounters* __restrict__ ctr, int d, int min_internal)
+// Read-back only (nbody_bh_tree_nodes): the box {tlX, tlY, brX, brY} of every node, recomputed from the topology —
+// climb to the root collecting quadrant digits, then replay the reference's midpoint arithmetic downwards.  The
+// step itself never needs boxes (the walk reads the width from A.w), so they are not stored by the build.
+__global__ __launch_bounds__(kBhBlock) void bh_box_kernel(BhTree t, const BhCounters* __restrict__ ctr, float4* __restrict__ box,
+                                                          int64_t count)
 {
-    const int c = blockIdx.x * kBhBlock + threadIdx.x;
-    if (ctr->internal <= min_internal) return;                  // done by bh_com_small_kernel
-    if (c >= ctr->internal || t.depth[c] != d) return;
+    const int64_t node = (int64_t)blockIdx.x * kBhBlock + threadIdx.x;
+    if (node >= count) return;
+    uint64_t path = 0;
+    int depth = 0;
+    for (int64_t v = node; v != 0 && depth < kBhLevels + 1; ++depth) {
+        path |= (uint64_t)((v - 1) & 3) << (2 * depth);       // digit of the LAST step first
+        v = t.self[(v - 1) >> 2];
+    }
+    const float h = ctr->root_half;
+    float tlx = -h, tly = -h, brx = h, bry = h;
+    for (int l = depth - 1; l >= 0; --l) {
+        const int q = (int)((path >> (2 * l)) & 3);
+        const float mx = (tlx + brx) / 2.0f, my = (tly + bry) / 2.0f;
+        if (q & 1) tlx = mx; else brx = mx;
+        if (q & 2) tly = my; else bry = my;
+    }
+    box[node] = make_float4(tlx, tly, brx, bry);
+}
+
+// 5. centre of mass, one launch per depth (deepest first) ---------------------------------------------------
+__device__ __forceinline__ void bh_com_cell(const BhTree& t, int c)
+{
     const int self = t.self[c];
     float ms = 0.0f, sx = 0.0f, sy = 0.0f;
 #pragma unroll
@@ -376,6 +417,21 @@ __global__ __launch_bounds__(kBhBlock) void bh_com_kernel(BhTree t, const BhCoun
     r.z = ms;
     if (ms > 0.0f) { r.x = sx / ms; r.y = sy / ms; }            // benchmark.cpp:137-141 (IEEE division)
     t.A[self] = r;
+}
+
+// One thread per 4 cells (one 32-bit load of their depth bytes): a quarter of the threads of a launch per pool
+// slot, short serial tails.
+__global__ __launch_bounds__(kBhBlock) void bh_com_kernel(BhTree t, const BhCounters* __restrict__ ctr, int d, int min_internal)
+{
+    const int I = ctr->internal;
+    if (I <= min_internal) return;                              // done by bh_com_small_kernel
+    const int c4 = (blockIdx.x * kBhBlock + threadIdx.x) * 4;
+    if (c4 >= I) return;
+    const unsigned x = *reinterpret_cast<const unsigned*>(t.depth + c4) ^ (0x01010101u * (unsigned)d);
+    if (((x - 0x01010101u) & ~x & 0x80808080u) == 0) return;    // no zero byte = no cell of depth d here
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (((x >> (8 * k)) & 0xFFu) == 0 && c4 + k < I) bh_com_cell(t, c4 + k);
 }
 
 // Small trees: all depths in ONE launch of one workgroup (31 launches of a few microseconds each are most of a

@@ -95,6 +95,8 @@ struct nbody_ctx {
         uint64_t *keys = nullptr, *keys_sorted = nullptr, *gkeys = nullptr, *gkeys_sorted = nullptr, *keys_merged = nullptr;
         int *vals = nullptr, *vals_sorted = nullptr, *gvals = nullptr, *gvals_sorted = nullptr, *vals_merged = nullptr;
         int *cnt = nullptr, *base = nullptr;
+        int* owner = nullptr;            // per internal cell: the sorted instance that owns it
+        uint16_t* tie = nullptr;         // per body: first levels at which x / y sit on a split line
         int gcap = 0;                    // capacity for second instances of bodies on split lines
         void* gsort_tmp = nullptr;
         size_t gsort_bytes = 0;
@@ -218,12 +220,12 @@ int enqueue_bh_build(nbody_ctx* ctx)
     const bool adaptive = ctx->cfg.adaptive_box != 0;
     bh_reset_kernel<<<1, 64, 0, s>>>(b.ctr, adaptive ? 1e-30f : ctx->cfg.spread);
     if (adaptive) bh_bounds_kernel<<<dim3(grid_n.x < 1024u ? grid_n.x : 1024u), blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr);
-    bh_keys_kernel<<<grid_n, blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr, b.keys, b.vals);
+    bh_keys_kernel<<<grid_n, blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr, b.keys, b.vals, b.tie);
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, b.keys, b.keys_sorted, b.vals, b.vals_sorted, n,
                                                0, 64, s));
     bh_valid_kernel<<<1, 64, 0, s>>>(b.keys_sorted, n, b.ctr);
     // bodies exactly on a split line get a second instance (inclusive bounds, benchmark.cpp:83-85)
-    bh_ties_kernel<<<grid_n, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.ctr, b.gkeys, b.gvals, b.gcap);
+    bh_ties_kernel<<<grid_n, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, b.gkeys, b.gvals, b.gcap);
     bh_ghost_pad_kernel<<<grid_g, blk, 0, s>>>(b.ctr, b.gkeys, b.gvals, b.gcap);
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.gsort_tmp, b.gsort_bytes, b.gkeys, b.gkeys_sorted, b.gvals, b.gvals_sorted,
                                                b.gcap, 0, 64, s));
@@ -233,7 +235,8 @@ int enqueue_bh_build(nbody_ctx* ctx)
     bh_count_kernel<<<grid_m, blk, 0, s>>>(b.keys_merged, nm, b.ctr, b.cnt);
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b.scan_tmp, b.scan_bytes, b.cnt, b.base, nm, s));
     const dim3 grid_c((b.tree.cap_internal + kBhBlock - 1) / kBhBlock);
-    bh_nodes_kernel<<<grid_c, blk, 0, s>>>(b.keys_merged, b.vals_merged, b.cnt, b.base, nm, ctx->m, ctx->px, ctx->py,
+    bh_owner_kernel<<<grid_m, blk, 0, s>>>(b.cnt, b.base, nm, b.ctr, b.owner, b.tree.cap_internal);
+    bh_nodes_kernel<<<grid_c, blk, 0, s>>>(b.keys_merged, b.vals_merged, b.cnt, b.base, b.owner, nm, ctx->m, ctx->px, ctx->py,
                                            b.tree, b.ctr);
     // centre of mass: ONE single-workgroup launch covers trees of <= kComSmall internal cells (the cell count is
     // only known on the device, so the kernels decide there which of the two paths runs); per-depth launches
@@ -241,9 +244,11 @@ int enqueue_bh_build(nbody_ctx* ctx)
     constexpr int kComSmall = 32768;
     const bool maybe_small = n <= 8 * kComSmall;
     if (maybe_small) bh_com_small_kernel<<<1, kBhComBlock, 0, s>>>(b.tree, b.ctr, kComSmall);
-    if (b.tree.cap_internal > kComSmall)
+    if (b.tree.cap_internal > kComSmall) {
+        const dim3 grid_com((unsigned)((b.tree.cap_internal + 4 * kBhBlock - 1) / (4 * kBhBlock)));
         for (int d = kBhLevels - 1; d >= 0; --d)
-            bh_com_kernel<<<grid_c, blk, 0, s>>>(b.tree, b.ctr, d, maybe_small ? kComSmall : -1);
+            bh_com_kernel<<<grid_com, blk, 0, s>>>(b.tree, b.ctr, d, maybe_small ? kComSmall : -1);
+    }
     HIP_TRY(hipGetLastError());
     return profile_end(ctx, 2, ep);
 }
@@ -398,6 +403,7 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
         HIP_TRY_C(hipMalloc((void**)&b.keys, sizeof(uint64_t) * (size_t)n));
         HIP_TRY_C(hipMalloc((void**)&b.keys_sorted, sizeof(uint64_t) * (size_t)n));
         HIP_TRY_C(hipMalloc((void**)&b.vals, sizeof(int) * (size_t)n));
+        HIP_TRY_C(hipMalloc((void**)&b.tie, sizeof(uint16_t) * (size_t)n));
         HIP_TRY_C(hipMalloc((void**)&b.vals_sorted, sizeof(int) * (size_t)n));
         b.gcap = n / 256 > 4096 ? n / 256 : 4096;
         const size_t nm = (size_t)n + (size_t)b.gcap;
@@ -411,8 +417,8 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
         HIP_TRY_C(hipMalloc((void**)&b.base, sizeof(int) * nm));
         HIP_TRY_C(hipMalloc((void**)&b.tree.A, sizeof(float4) * (size_t)b.node_cap));
         HIP_TRY_C(hipMalloc((void**)&b.tree.B, sizeof(int2) * (size_t)b.node_cap));
-        HIP_TRY_C(hipMalloc((void**)&b.tree.box, sizeof(float4) * (size_t)b.node_cap));
-        HIP_TRY_C(hipMalloc((void**)&b.tree.depth, (size_t)b.tree.cap_internal));
+        HIP_TRY_C(hipMalloc((void**)&b.owner, sizeof(int) * (size_t)b.tree.cap_internal));
+        HIP_TRY_C(hipMalloc((void**)&b.tree.depth, (size_t)b.tree.cap_internal + 16));   // read 16 bytes at a time
         HIP_TRY_C(hipMalloc((void**)&b.tree.self, sizeof(int) * (size_t)b.tree.cap_internal));
         HIP_TRY_C(hipMalloc((void**)&b.ctr, sizeof(BhCounters)));
         HIP_TRY_C(hipMemset(b.ctr, 0, sizeof(BhCounters)));
@@ -440,8 +446,8 @@ void nbody_destroy(nbody_ctx* ctx)
     if (ctx->diag_partials) (void)hipFree(ctx->diag_partials);
     {
         auto& b = ctx->bh;
-        void* ptrs[] = {b.keys, b.keys_sorted, b.vals, b.vals_sorted, b.cnt, b.base, b.tree.A, b.tree.B, b.tree.box,
-                        b.tree.depth, b.tree.self, b.ctr, b.sort_tmp, b.scan_tmp, b.gkeys, b.gkeys_sorted, b.gvals,
+        void* ptrs[] = {b.keys, b.keys_sorted, b.vals, b.vals_sorted, b.cnt, b.base, b.tree.A, b.tree.B,
+                        b.tree.depth, b.tree.self, b.ctr, b.tie, b.owner, b.sort_tmp, b.scan_tmp, b.gkeys, b.gkeys_sorted, b.gvals,
                         b.gvals_sorted, b.keys_merged, b.vals_merged, b.gsort_tmp};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -831,7 +837,13 @@ int64_t nbody_bh_tree_nodes(nbody_ctx* ctx, void* out, int64_t cap)
     std::vector<int2> B((size_t)k);
     HIP_TRY(hipMemcpy(A.data(), ctx->bh.tree.A, sizeof(float4) * (size_t)k, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(B.data(), ctx->bh.tree.B, sizeof(int2) * (size_t)k, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(box.data(), ctx->bh.tree.box, sizeof(float4) * (size_t)k, hipMemcpyDeviceToHost));
+    float4* dbox = nullptr;                                    // boxes are not kept by the build: recompute them
+    HIP_TRY(hipMalloc((void**)&dbox, sizeof(float4) * (size_t)k));
+    bh_box_kernel<<<dim3((unsigned)((k + kBhBlock - 1) / kBhBlock)), dim3(kBhBlock), 0, ctx->stream>>>(ctx->bh.tree, ctx->bh.ctr, dbox, k);
+    hipError_t be = hipStreamSynchronize(ctx->stream);
+    if (be == hipSuccess) be = hipMemcpy(box.data(), dbox, sizeof(float4) * (size_t)k, hipMemcpyDeviceToHost);
+    (void)hipFree(dbox);
+    HIP_TRY(be);
     struct QuadNodeRecord {   // layout of the reference's QuadNode, benchmark.cpp:52-60
         float mass, comX, comY, tlX, tlY, brX, brY;
         int32_t bodyIndex, children[4];
