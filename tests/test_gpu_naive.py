@@ -204,6 +204,28 @@ def test_n1m_full_size_properties(nb, O):
     assert tot <= 1e-5 * np.sum(np.hypot(ax, ay).astype(np.float64))
 
 
+def test_n1m_exact_symmetries(nb, O):
+    """Size-independent EXACT properties at the metric's full size (N = 2^20), bit for bit:
+    * mirror: negating every x negates ax and leaves ay unchanged (IEEE operations are sign-symmetric and the
+      pair order does not depend on the data);
+    * axis swap: exchanging the x and y arrays exchanges ax and ay except for the one place where the kernel is
+      not symmetric in x and y — d2 = fma(dx,dx, fma(dy,dy,eps)) — so this one is gated at 5e-6 (measured 1.5e-6), not exact;
+    * mass linearity: doubling every mass doubles every acceleration (power-of-two scaling is exact)."""
+    n = 1 << 20
+    b = O.init_disc(n, seed=12345)
+    ax, ay, _, _ = run_gpu(nb, b)
+    mir = b.copy(); mir.posX = -mir.posX
+    mx, my, _, _ = run_gpu(nb, mir)
+    assert np.array_equal(mx, -ax) and np.array_equal(my, ay)
+    dbl = b.copy(); dbl.m = dbl.m * 2.0
+    dx, dy, _, _ = run_gpu(nb, dbl)
+    assert np.array_equal(dx, 2.0 * ax) and np.array_equal(dy, 2.0 * ay)
+    swp = b.copy(); swp.posX, swp.posY = b.posY.copy(), b.posX.copy()
+    sx, sy, _, _ = run_gpu(nb, swp)
+    e = rel_err(sx, sy, ay, ax)
+    assert e.max() <= 5e-6, e.max()
+
+
 def test_diagnostics_vs_oracle(nb, O):
     b = O.init_disc(4096, seed=31)
     b.posX *= 0.2; b.posY *= 0.2            # both potential branches populated
