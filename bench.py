@@ -210,6 +210,13 @@ def main():
                                  "20 x owned targets x N sources per launch (rank 0); integrate_kernel "
                                  f"{integ_ms / max(1, integ_launches) * 1e3:.1f} us/launch"},
         }
+        # second kernel of the step: j-slice reduction + Euler, HBM-bound.  Algorithmic bytes per owned target:
+        # 8 B per slice partial + 16 B (pos, vel) read, 24 B (acc, pos, vel) written (40 B unfused)
+        i_ms = integ_ms / max(1, integ_launches)
+        i_gbs = (8.0 * info["j_slices"] + 40.0) * my_targets / (i_ms * 1e-3) / 1e9 if i_ms > 0 else 0.0
+        line["roofline_integrate"] = {"bound": "hbm", "achieved": i_gbs, "peak": 8000.0, "unit": "GB/s", "frac": i_gbs / 8000.0,
+                                      "traffic": None, "kernel": "integrate_kernel", "kernel_ms": i_ms,
+                                      "launches": int(integ_launches)}
         if world == 1 and n == 1 << 20 and info["j_slices"] == 8:
             # HBM bytes per force launch from the committed PMC passes of this very command (FETCH_SIZE KiB x2 on
             # gfx950 + WRITE_SIZE KiB); counters cannot be read from inside the process, so this is not live
