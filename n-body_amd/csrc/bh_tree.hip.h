@@ -56,6 +56,7 @@ struct BhCounters {          // device-resident scalars of one build/walk
     int overflow;            // node pool (1) or tie-instance buffer (2) too small
     int ghosts;              // G: second instances of bodies on split lines
     unsigned long long visits, accepts;
+    unsigned long long wave_iters;   // walk: loop iterations summed over waves (lane utilisation = visits / (8 * wave_iters))
     float root_half;         // half-width h of the root box [-h,h]^2 of this build (= spread unless adaptive)
     int pad_;
 };
@@ -132,6 +133,7 @@ __global__ void bh_reset_kernel(BhCounters* __restrict__ ctr, float root_half0)
     ctr->ghosts = 0;
     ctr->visits = 0;
     ctr->accepts = 0;
+    ctr->wave_iters = 0;
 }
 
 // Adaptive root box (opt-in, nbody_config.adaptive_box): h = max_i max(|x_i|,|y_i|) over finite positions.
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     // pushes/pops, so each lane writes the value it will later read back itself (same address, same value): no
     // cross-lane ordering is needed and 4.3 KB of LDS per workgroup leaves room for 8 waves per SIMD.
     __shared__ int stack[kBhStackDepth][kBhBlock / 8];
-    __shared__ unsigned long long red[2][kBhBlock / 64];
+    __shared__ unsigned long long red[3][kBhBlock / 64];
     const int tid = threadIdx.x;
     const int i = w.i_begin + blockIdx.x * kBhBlock + tid;
     const bool live = i < w.i_end;
@@ -507,10 +509,15 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     int node = 0, sp = 0;
     float4 a = w.A[0];
     int2 b = w.B[0];
+    unsigned iters = 0;
     while (__any(active)) {
+        ++iters;
         if (active) {
             // (Tried: requesting the records of both likely successors — next sibling and last child — before this
-            // node's arithmetic.  Same-box A/B: no gain at N = 10^4..65 536, 28 % slower at N = 10^6; not kept.)
+            // node's arithmetic.  Same-box A/B: no gain at N = 10^4..65 536, 28 % slower at N = 10^6; not kept.
+            // Tried: the whole body as straight-line predicated code (selects instead of nested branches): 110 ->
+            // 75 instructions per iteration, but the divisions then run for every group in every iteration:
+            // +8 % at N = 10^6 (IEEE) / +4 % (fast math), -14 % at N = 10^4; not kept.)
             const bool more_siblings = node != 0 && ((node - 1) & 3) != 0;
             ++visits;
             bool open = false;
@@ -571,13 +578,14 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     // counters: one representative lane per group
     unsigned long long v = (tid & 7) == 0 ? visits : 0, acc = (tid & 7) == 0 ? accepts : 0;
     for (int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); acc += __shfl_down(acc, off, 64); }
-    if ((tid & 63) == 0) { red[0][tid >> 6] = v; red[1][tid >> 6] = acc; }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = v; red[1][tid >> 6] = acc; red[2][tid >> 6] = iters; }
     __syncthreads();
     if (tid == 0) {
-        unsigned long long sv = 0, sa = 0;
-        for (int k = 0; k < kBhBlock / 64; ++k) { sv += red[0][k]; sa += red[1][k]; }
+        unsigned long long sv = 0, sa = 0, si = 0;
+        for (int k = 0; k < kBhBlock / 64; ++k) { sv += red[0][k]; sa += red[1][k]; si += red[2][k]; }
         atomicAdd(&w.ctr->visits, sv);
         atomicAdd(&w.ctr->accepts, sa);
+        atomicAdd(&w.ctr->wave_iters, si);
     }
 }
 

@@ -869,6 +869,9 @@ int nbody_bh_counters(nbody_ctx* ctx, int64_t out[2])
     HIP_TRY(hipMemcpy(&h, ctx->bh.ctr, sizeof(h), hipMemcpyDeviceToHost));
     out[0] = (int64_t)h.visits;
     out[1] = (int64_t)h.accepts;
+    if (std::getenv("NBODY_DEBUG"))
+        std::fprintf(stderr, "[nbody] walk: %llu group-visits in %llu wave iterations: %.1f %% of the 8 group slots busy\n",
+                     h.visits, h.wave_iters, h.wave_iters ? 100.0 * (double)h.visits / (8.0 * (double)h.wave_iters) : 0.0);
     return NBODY_OK;
 }
 
