@@ -119,14 +119,14 @@ def main():
 
     pkg = entry.load_package()
     from nbody_amd.sharded import ShardedSim, owned_targets
-    O = entry.load_oracle()          # only for the synthetic inputs (seeded disc) and the cpu_baseline leg
+    from nbody_amd.initial_conditions import disc
     n = args.n
-    bodies = O.init_disc(n, seed=12345)      # benchmark.cpp:317-339, seed fixed
+    bodies = disc(n, seed=12345)             # benchmark.cpp:317-339, seed fixed; (m, posX, posY, velX, velY, radius)
 
     bh = args.workload == "bh"
     sim = ShardedSim(pkg, n, rank, world, device=local_rank, dt=0.05, dist=dist, useBarnesHut=bh, theta=args.theta,
                      bh_fast_math=bh and args.bh_fast_math)
-    sim.upload(*bodies.arrays())
+    sim.upload(*bodies)
     my_targets = owned_targets(n, sim.spans, rank)
 
     def barrier():
@@ -140,7 +140,7 @@ def main():
         # The reference's disc is unbound (velocity factor 0.3): within ~10 steps most bodies have left the fixed
         # root box and the walk shrinks (SURVEY.md §6.2, §8d "time steps 1-5 only").  Warm-up therefore runs on the
         # same context (graph captured, clocks up) and the INITIAL state is uploaded again before the timed steps.
-        sim.upload(*bodies.arrays())
+        sim.upload(*bodies)
         barrier()
     # naive: per-kernel hipEvent timing stays on inside the timed region (2 launches per step, ~180 ms each).
     # Barnes-Hut: the timed region runs the captured hipGraph (no event pairs inside a capture); the per-kernel
@@ -152,7 +152,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if bh:
-        sim.upload(*bodies.arrays())
+        sim.upload(*bodies)
         sim.sim.profile(True).profile_reset()
         sim.step(1)                    # per-kernel times and the visit counters both describe step 1
         barrier()
@@ -216,7 +216,9 @@ def main():
         i_gbs = (8.0 * info["j_slices"] + 40.0) * my_targets / (i_ms * 1e-3) / 1e9 if i_ms > 0 else 0.0
         line["roofline_integrate"] = {"bound": "hbm", "achieved": i_gbs, "peak": 8000.0, "unit": "GB/s", "frac": i_gbs / 8000.0,
                                       "traffic": None, "kernel": "integrate_kernel", "kernel_ms": i_ms,
-                                      "launches": int(integ_launches)}
+                                      "launches": int(integ_launches),
+                                      "note": "hipEvent pairs add ~4 us to a kernel this short: rocprofv3 shows 18.9 us = 5.8 TB/s "
+                                              "for the same launch (profiles/README.md)"}
         if world == 1 and n == 1 << 20 and info["j_slices"] == 8:
             # HBM bytes per force launch from the committed PMC passes of this very command (FETCH_SIZE KiB x2 on
             # gfx950 + WRITE_SIZE KiB); counters cannot be read from inside the process, so this is not live

@@ -185,3 +185,19 @@ int main() { nbody_host::BodyStore b; nbody_host::fill_disc(b, 1024, 400.0f, 100
     b = O.init_disc(1024, seed=12345)
     assert np.array_equal(a[0], b.posX) and np.array_equal(a[1], b.posY)
     assert np.allclose(a[2], b.velX, rtol=1e-6, atol=1e-7) and np.allclose(a[3], b.velY, rtol=1e-6, atol=1e-7)
+
+
+def test_python_generator_equals_oracle_generator(O):
+    """n-body_amd/initial_conditions.py (bench.py's synthetic inputs) against the oracle's restatement of
+    benchmark.cpp:312-339, itself pinned to the compiled reference by tests/test_oracle.py: bit for bit."""
+    import __graft_entry__ as entry
+    entry.load_package()
+    from nbody_amd.initial_conditions import disc
+    for n, seed in ((1000, 12345), (4099, 7)):
+        got = disc(n, seed=seed)
+        want = O.init_disc(n, seed=seed)
+        for a, f in zip(got, ("m", "posX", "posY", "velX", "velY", "radius")):
+            assert a.dtype == np.float32 and np.array_equal(a, getattr(want, f)), f
+    slow = disc(256, seed=3, vel_factor=0.05)             # main.cpp:431-432
+    fast = disc(256, seed=3, vel_factor=0.3)
+    assert np.allclose(slow[3] * 6.0, fast[3], rtol=1e-6)

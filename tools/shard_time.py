@@ -4,11 +4,12 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as e
-nb = e.load_package(); O = e.load_oracle()
+nb = e.load_package()
+from nbody_amd import initial_conditions as ic
 n = 1 << 20
-b = O.init_disc(n, seed=12345)
+b = ic.disc(n, seed=12345)
 for P in (1, 2, 4, 8):
-    sim = nb.NBodySim(n, shard=nb.shard_range(n, P, P - 1)); sim.upload(*b.arrays())
+    sim = nb.NBodySim(n, shard=nb.shard_range(n, P, P - 1)); sim.upload(*b)
     sim.step(1).sync()
     sim.profile(True).profile_reset()
     reps = 3

@@ -8,10 +8,11 @@ CODE = r'''
 import sys, time, numpy as np
 sys.path.insert(0, %r)
 import __graft_entry__ as e
-nb = e.load_package(); O = e.load_oracle()
+nb = e.load_package()
+from nbody_amd import initial_conditions as ic
 n = int(sys.argv[1]); reps = int(sys.argv[2])
-b = O.init_disc(n, seed=12345)
-sim = nb.NBodySim(n, useBarnesHut=False); sim.upload(*b.arrays())
+b = ic.disc(n, seed=12345)
+sim = nb.NBodySim(n, useBarnesHut=False); sim.upload(*b)
 sim.compute_accel(); sim.sync()
 sim.profile(True).profile_reset()
 for _ in range(reps): sim.compute_accel()
