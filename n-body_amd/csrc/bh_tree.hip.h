@@ -476,7 +476,21 @@ struct BhWalkArgs {
     BhCounters* __restrict__ ctr;
     int i_begin, i_end;              // targets; i_begin is a multiple of 8
     float theta;
+    int lanes_used;                  // 8 x groups per wave (64, 32, 16 or 8): see bh_walk_groups_per_wave()
 };
+
+// Groups per wave.  8 (all 64 lanes) is the throughput shape.  With few groups the walk is a latency chain and the
+// chip is mostly idle, so each wave then takes fewer groups: more waves in flight and a wave no longer executes the
+// accept AND the open AND the pop path of 8 diverging groups in every iteration.
+inline int bh_walk_groups_per_wave(int targets)
+{
+    const int groups = (targets + 7) / 8;
+    int g = 8;
+    while (g > 1 && groups / g < 1024) g >>= 1;     // one wave per SIMD (256 CUs x 4); more waves than that only
+                                                    // multiply the instruction stream (measured: 2 groups/wave at
+                                                    // N = 65 536 is 28 % slower than 8)
+    return g;
+}
 
 // kFast = false: IEEE sqrt and divisions everywhere; every lane reproduces oracle_bh_accel() bit for bit.
 // kFast = true (nbody_config.bh_fast_math): the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32.  The VOTE stays the
@@ -493,8 +507,10 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     __shared__ int stack[kBhStackDepth][kBhBlock / 8];
     __shared__ unsigned long long red[3][kBhBlock / 64];
     const int tid = threadIdx.x;
-    const int i = w.i_begin + blockIdx.x * kBhBlock + tid;
-    const bool live = i < w.i_end;
+    // wave v of the grid walks groups [v*G, (v+1)*G), G = lanes_used/8, on its first lanes_used lanes
+    const int lane = tid & 63;
+    const int i = w.i_begin + (blockIdx.x * (kBhBlock / 64) + (tid >> 6)) * w.lanes_used + lane;
+    const bool live = lane < w.lanes_used && i < w.i_end;
     const int ic = live ? i : w.i_end - 1;
     const float xi = w.px[ic], yi = w.py[ic], ri = w.radius[ic];
     const int grp_shift = (tid & 63) & ~7;                      // first lane of this group inside the wave

@@ -265,7 +265,9 @@ int enqueue_bh_walk(nbody_ctx* ctx)
     EventPair* ep;
     int rc = profile_begin(ctx, 0, &ep);
     if (rc) return rc;
-    const dim3 grid((nt + kBhBlock - 1) / kBhBlock), blk(kBhBlock);
+    w.lanes_used = 8 * bh_walk_groups_per_wave(nt);
+    const int per_block = (kBhBlock / 64) * w.lanes_used;      // targets per workgroup
+    const dim3 grid((nt + per_block - 1) / per_block), blk(kBhBlock);
     if (ctx->cfg.bh_fast_math) bh_walk_kernel<true><<<grid, blk, 0, ctx->stream>>>(w);
     else                       bh_walk_kernel<false><<<grid, blk, 0, ctx->stream>>>(w);
     HIP_TRY(hipGetLastError());
