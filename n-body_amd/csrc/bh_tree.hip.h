@@ -415,10 +415,12 @@ __device__ __forceinline__ void bh_com_cell(const BhTree& t, int c)
         sx = __builtin_fmaf(a.x, a.z, sx);
         sy = __builtin_fmaf(a.y, a.z, sy);
     }
-    float4 r = t.A[self];
-    r.z = ms;
-    if (ms > 0.0f) { r.x = sx / ms; r.y = sy / ms; }            // benchmark.cpp:137-141 (IEEE division)
-    t.A[self] = r;
+    // benchmark.cpp:137-141 (IEEE division; an all-massless cell keeps the (0,0) bh_nodes_kernel gave it).  Only
+    // {comX, comY, mass} are written: the width in .w stays, so the record is not read first (one round trip less
+    // per level of the bottom-up chain).
+    float* rec = reinterpret_cast<float*>(t.A + self);
+    const float cx = ms > 0.0f ? sx / ms : 0.0f, cy = ms > 0.0f ? sy / ms : 0.0f;
+    rec[0] = cx; rec[1] = cy; rec[2] = ms;
 }
 
 // One thread per 4 cells (one 32-bit load of their depth bytes): a quarter of the threads of a launch per pool
@@ -443,23 +445,19 @@ __global__ __launch_bounds__(kBhComBlock) void bh_com_small_kernel(BhTree t, con
 {
     const int I = ctr->internal;
     if (I > max_internal) return;
-    for (int d = kBhLevels - 1; d >= 0; --d) {
-        for (int c = threadIdx.x; c < I; c += kBhComBlock) {
-            if (t.depth[c] != d) continue;
-            const int self = t.self[c];
-            float ms = 0.0f, sx = 0.0f, sy = 0.0f;
+    // each thread keeps the depths of its (at most kPer) cells in registers: the level loop then touches memory
+    // only for the cells of that level
+    constexpr int kPer = 32;                                    // max_internal <= kPer * kBhComBlock
+    uint8_t dl[kPer];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 a = t.A[1 + 4 * c + q];
-                ms = ms + a.z;
-                sx = __builtin_fmaf(a.x, a.z, sx);
-                sy = __builtin_fmaf(a.y, a.z, sy);
-            }
-            float4 r = t.A[self];
-            r.z = ms;
-            if (ms > 0.0f) { r.x = sx / ms; r.y = sy / ms; }
-            t.A[self] = r;
-        }
+    for (int k = 0; k < kPer; ++k) {
+        const int c = threadIdx.x + k * kBhComBlock;
+        dl[k] = c < I ? t.depth[c] : (uint8_t)0xFF;
+    }
+    for (int d = kBhLevels - 1; d >= 0; --d) {                 // a level without cells costs one barrier
+#pragma unroll
+        for (int k = 0; k < kPer; ++k)
+            if (dl[k] == d) bh_com_cell(t, threadIdx.x + k * kBhComBlock);
         __syncthreads();        // one workgroup: a barrier (with its LDS/global fence) orders level d before d-1
     }
 }
