@@ -13,7 +13,7 @@ lib: $(LIB)
 
 $(LIB): $(CSRC)/nbody_capi.hip $(KERNEL_HDRS)
 	@mkdir -p $(PKG)/lib
-	$(HIPCC) $(HIPFLAGS) -shared $< -o $@
+	$(HIPCC) $(HIPFLAGS) -shared $< -o $@ -ldl
 
 # C++ host drivers: counterparts of the reference's benchmark.cpp / main.cpp loops, calling the C-ABI.
 host: $(PKG)/bin/nbody_benchmark $(PKG)/bin/nbody_sim

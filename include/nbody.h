@@ -101,6 +101,19 @@ int nbody_sync(nbody_ctx *ctx);
 /* Copies the state back (syncs).  Any pointer may be NULL.  main.cpp:650-653 needs posX/posY only. */
 int nbody_download(nbody_ctx *ctx, float *posX, float *posY, float *velX, float *velY);
 
+/* Native position exchange for sharded contexts (no reference counterpart): RCCL straight from the
+   library, for hosts without a framework.  One process per GPU: rank 0 calls nbody_comm_unique_id and hands the 128
+   bytes to the other ranks by any means (the C++ driver uses a TCP socket); every rank calls nbody_comm_init on a
+   context whose shard is nbody_shard_range(N, nranks, rank); then, after each nbody_step(ctx, 1),
+   nbody_exchange_positions enqueues the all-gather of posX/posY (in-place ncclAllGather; one ncclBroadcast per
+   owner when the shards are ragged) on the context's stream.  RCCL is loaded at run time (librccl.so, or the path in
+   NBODY_RCCL_LIB); NBODY_ERR_UNSUPPORTED if it cannot be.  Frameworks that own a process group can instead gather
+   nbody_device_ptr(ctx, 1|2) themselves, as n-body_amd/sharded.py does with torch.distributed. */
+#define NBODY_COMM_ID_BYTES 128
+int nbody_comm_unique_id(char out[NBODY_COMM_ID_BYTES]);
+int nbody_comm_init(nbody_ctx *ctx, int32_t rank, int32_t nranks, const char id[NBODY_COMM_ID_BYTES]);
+int nbody_exchange_positions(nbody_ctx *ctx);
+
 /* Position streaming for a viewer (the consumer is the per-frame draw loop main.cpp:646-655,
    which reads posX/posY only).  nbody_frame_publish enqueues, behind the steps enqueued so far, a device-side
    snapshot of posX/posY and its asynchronous copy into library-owned PINNED host memory on a separate copy

@@ -22,7 +22,7 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 ABI_SYMBOLS = (
     "nbody_default_config", "nbody_shard_range", "nbody_create", "nbody_destroy", "nbody_set_stream",
     "nbody_upload", "nbody_step", "nbody_compute_accel", "nbody_sync", "nbody_download", "nbody_frame_publish",
-    "nbody_frame_acquire", "nbody_get_accel",
+    "nbody_frame_acquire", "nbody_comm_unique_id", "nbody_comm_init", "nbody_exchange_positions", "nbody_get_accel",
     "nbody_diagnostics", "nbody_device_ptr", "nbody_profile_enable", "nbody_profile_read",
     "nbody_profile_reset", "nbody_get_info", "nbody_bh_tree_nodes", "nbody_bh_counters",
     "nbody_last_error", "nbody_abi_version",
@@ -69,6 +69,9 @@ def lib():
         L.nbody_download.argtypes = [C.c_void_p] + [_f32p] * 4
         L.nbody_frame_publish.argtypes = [C.c_void_p]
         L.nbody_frame_acquire.argtypes = [C.c_void_p, C.POINTER(_f32p), C.POINTER(_f32p), C.POINTER(C.c_int64)]
+        L.nbody_comm_unique_id.argtypes = [C.c_char_p]
+        L.nbody_comm_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]
+        L.nbody_exchange_positions.argtypes = [C.c_void_p]
         L.nbody_get_accel.argtypes = [C.c_void_p, _f32p, _f32p]
         L.nbody_diagnostics.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.nbody_device_ptr.argtypes = [C.c_void_p, C.c_int32]
@@ -102,6 +105,13 @@ def shard_range(num_bodies, nranks, rank):
     b, c = C.c_int32(), C.c_int32()
     _check(lib().nbody_shard_range(num_bodies, nranks, rank, C.byref(b), C.byref(c)))
     return b.value, c.value
+
+
+def comm_unique_id():
+    """128-byte RCCL id, created by rank 0 and handed to every rank's NBodySim.comm_init (nbody_comm_unique_id)."""
+    buf = C.create_string_buffer(128)
+    _check(lib().nbody_comm_unique_id(buf))
+    return buf.raw
 
 
 def _as_f32(a, n, name):
@@ -169,6 +179,15 @@ class NBodySim:
         px, py, step = _f32p(), _f32p(), C.c_int64()
         _check(lib().nbody_frame_acquire(self._h, C.byref(px), C.byref(py), C.byref(step)))
         return (np.ctypeslib.as_array(px, shape=(self.n,)), np.ctypeslib.as_array(py, shape=(self.n,)), step.value)
+
+    # -- native RCCL exchange (hosts without a framework; sharded.py uses torch.distributed instead) -----------
+    def comm_init(self, rank, nranks, unique_id):
+        _check(lib().nbody_comm_init(self._h, int(rank), int(nranks), bytes(unique_id)))
+        return self
+
+    def exchange_positions(self):
+        _check(lib().nbody_exchange_positions(self._h))
+        return self
 
     def accel(self):
         ax, ay = np.empty(self.n, np.float32), np.empty(self.n, np.float32)

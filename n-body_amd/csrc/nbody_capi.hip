@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <vector>
 
 using namespace nbody;
@@ -75,6 +76,10 @@ struct nbody_ctx {
     bool uploaded = false;
     int64_t steps_enqueued = 0;      // since the last upload
     Profiler prof;
+    // native exchange (comm_rccl.hip.h): an ncclComm_t, kept as void* so that this struct needs no RCCL header
+    void* comm = nullptr;
+    int comm_rank = 0, comm_nranks = 1;
+    std::vector<std::pair<int, int>> comm_spans;   // (begin, count) of every rank
     // position streaming (nbody_frame_*): device snapshots + pinned host frames, copied on their own stream
     struct Frames {
         static constexpr int kSlots = 2;
@@ -107,6 +112,8 @@ struct nbody_ctx {
         int64_t node_cap = 0;
     } bh;
 };
+
+void destroy_comm(nbody_ctx* ctx);   // comm_rccl.hip.h
 
 namespace {
 
@@ -442,6 +449,7 @@ void nbody_destroy(nbody_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->step_graph) (void)hipGraphExecDestroy(ctx->step_graph);
+    destroy_comm(ctx);
     float* arrs[] = {ctx->m, ctx->px, ctx->py, ctx->vx, ctx->vy, ctx->radius, ctx->c, ctx->ax, ctx->ay, ctx->pax, ctx->pay};
     for (float* p : arrs)
         if (p) (void)hipFree(p);
@@ -882,3 +890,11 @@ const char* nbody_last_error(void) { return g_err; }
 int nbody_abi_version(void) { return NBODY_ABI_VERSION; }
 
 }  // extern "C"
+
+#include "comm_rccl.hip.h"
+
+void destroy_comm(nbody_ctx* ctx)
+{
+    if (ctx->comm && rccl_api().CommDestroy) (void)rccl_api().CommDestroy(static_cast<ncclComm_t>(ctx->comm));
+    ctx->comm = nullptr;
+}

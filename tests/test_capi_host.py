@@ -201,3 +201,26 @@ def test_python_generator_equals_oracle_generator(O):
     slow = disc(256, seed=3, vel_factor=0.05)             # main.cpp:431-432
     fast = disc(256, seed=3, vel_factor=0.3)
     assert np.allclose(slow[3] * 6.0, fast[3], rtol=1e-6)
+
+
+def test_cpp_driver_bootstrap_hands_the_comm_id_to_every_rank(tmp_path):
+    """nbody_benchmark --dist shares rank 0's 128-byte RCCL id over a TCP socket (MASTER_PORT + 1).  The hand-off
+    itself needs no GPU: three ranks, started in the wrong order, must all print the checksum of rank 0's bytes."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    exe = os.path.join(ROOT, "n-body_amd", "bin", "nbody_benchmark")
+    procs = []
+    for rank in (2, 1, 0):                                   # rank 0 last: the others have to retry
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port - 1))
+        procs.append(subprocess.Popen([exe, "--selftest-bootstrap"], env=env, cwd=str(tmp_path), stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=60) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    sums = {re.search(r"id checksum (\d+)", o[0]).group(1) for o in outs}
+    assert len(sums) == 1
+    want = 0
+    for k in range(128):
+        want = (want * 31 + ((k * 7 + 3) & 0xFF)) & 0xFFFFFFFF
+    assert sums == {str(want)}
