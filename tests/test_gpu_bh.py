@@ -311,6 +311,6 @@ def test_per_body_masses_radii_and_massless_bodies(nb, O):
         assert np.array_equal(cg, co)
         if fast:
             e = rel_err(ax, ay, ox, oy)
-            assert np.nanmedian(e) <= 2e-7 and np.nanmax(e) <= 1e-4      # random signs of m-weighted terms cancel more
+            assert np.nanmedian(e) <= 2e-7 and np.nanmax(e) <= 1e-4      # random masses: the terms of a body cancel more
         else:
             assert np.array_equal(ax, ox.astype(np.float32)) and np.array_equal(ay, oy.astype(np.float32))
