@@ -45,10 +45,12 @@ typedef struct nbody_config {
     int32_t use_barnes_hut;  /* useBarnesHut: 0 = naive O(N^2) (benchmark.cpp:405), 1 = BH (:354)  */
     int32_t use_parallel;    /* useParallel: in the BH branch 0 means "build tree, do nothing"
                                 (benchmark.cpp:359); ignored by the naive branch, as in the reference */
-    int32_t ref_compat;      /* 1: reproduce the reference's quirks — bodies with index >= N-N%8 are
-                                never targets nor integrated (benchmark.cpp:423,486,368) and the BH
-                                walk votes per group of 8 consecutive bodies (benchmark.cpp:264-266).
-                                0: every body is a target; BH walk still uses the group-of-8 vote.  */
+    int32_t ref_compat;      /* 1: reproduce benchmark.cpp's quirks — bodies with index >= N-N%8 are never targets
+                                nor integrated (benchmark.cpp:423,486,368) and the BH walk votes per group of 8
+                                consecutive bodies (benchmark.cpp:264-266).
+                                2: main.cpp's flavour of the same — identical, except that its Barnes-Hut branch lets
+                                the N%8 tail bodies drift force-free, pos += vel*dt (main.cpp:535-544).
+                                0: every body is a target; BH walk still uses the group-of-8 vote.                 */
     int32_t device;          /* HIP device ordinal; -1 = current device                           */
     /* i-body shard owned by this context (multi-GPU: one context per GPU/process).
        All num_bodies bodies are sources; targets are [shard_begin, shard_begin+shard_count).

@@ -146,7 +146,7 @@ class NBodySim:
         cfg = default_config()
         cfg.num_bodies, cfg.spread, cfg.mass, cfg.dt, cfg.theta = int(numBodies), spread, mass, dt, theta
         cfg.use_barnes_hut, cfg.use_parallel = int(bool(useBarnesHut)), int(bool(useParallel))
-        cfg.ref_compat, cfg.device, cfg.force_variant = int(bool(ref_compat)), int(device), int(force_variant)
+        cfg.ref_compat, cfg.device, cfg.force_variant = int(ref_compat), int(device), int(force_variant)
         cfg.adaptive_box, cfg.bh_fast_math = int(bool(adaptive_box)), int(bool(bh_fast_math))
         if shard is not None:
             cfg.shard_begin, cfg.shard_count = int(shard[0]), int(shard[1])

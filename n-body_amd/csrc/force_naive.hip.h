@@ -277,4 +277,14 @@ __global__ __launch_bounds__(256) void integrate_kernel(const IntegrateArgs a)
     }
 }
 
+// main.cpp:535-544: in its Barnes-Hut branch the N%8 tail bodies (never targets) still drift, with zero force
+__global__ void tail_drift_kernel(float* __restrict__ px, float* __restrict__ py, const float* __restrict__ vx,
+                                  const float* __restrict__ vy, int first, int n, float dt)
+{
+    const int i = first + (int)threadIdx.x;
+    if (i >= n) return;
+    px[i] = __builtin_fmaf(vx[i], dt, px[i]);
+    py[i] = __builtin_fmaf(vy[i], dt, py[i]);
+}
+
 }  // namespace nbody

@@ -195,6 +195,13 @@ int enqueue_force(nbody_ctx* ctx)
 
 int enqueue_integrate(nbody_ctx* ctx, int advance)
 {
+    // ref_compat 2 (main.cpp:535-544): the context that owns the end of the array lets the N%8 tail drift
+    const int n = ctx->cfg.num_bodies, tail = n % 8;
+    const int shard_end = ctx->cfg.shard_begin + (ctx->cfg.shard_count == 0 ? n - ctx->cfg.shard_begin : ctx->cfg.shard_count);
+    if (advance && tail && ctx->cfg.ref_compat == 2 && ctx->cfg.use_barnes_hut && shard_end == n) {
+        tail_drift_kernel<<<1, 8, 0, ctx->stream>>>(ctx->px, ctx->py, ctx->vx, ctx->vy, n - tail, n, ctx->cfg.dt);
+        HIP_TRY(hipGetLastError());
+    }
     if (ctx->i_end <= ctx->i_begin) return NBODY_OK;
     IntegrateArgs a{};
     a.px = ctx->px; a.py = ctx->py; a.vx = ctx->vx; a.vy = ctx->vy;

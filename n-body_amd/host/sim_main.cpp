@@ -70,6 +70,7 @@ int main(int argc, char** argv)
     cfg.dt = sc.dt;
     cfg.use_barnes_hut = sc.useBarnesHut;
     cfg.use_parallel = sc.useParallel;
+    cfg.ref_compat = 2;                      // main.cpp's handling of the N%8 tail (main.cpp:535-544)
     const int n = cfg.num_bodies;
 
     nbody_host::BodyStore data;

@@ -314,3 +314,31 @@ def test_per_body_masses_radii_and_massless_bodies(nb, O):
             assert np.nanmedian(e) <= 2e-7 and np.nanmax(e) <= 1e-4      # random masses: the terms of a body cancel more
         else:
             assert np.array_equal(ax, ox.astype(np.float32)) and np.array_equal(ay, oy.astype(np.float32))
+
+
+@pytest.mark.parametrize("n", [1003, 7])
+def test_ref_compat_2_is_main_cpp_tail_bodies_drift_force_free(nb, O, n):
+    """main.cpp's Barnes-Hut branch differs from benchmark.cpp's in one thing: the N%8 tail bodies, which are never
+    targets, still move, pos += vel*dt with zero force (main.cpp:535-544).  Everything else equals ref_compat=1."""
+    b = O.init_disc(n, seed=21)
+    k, dt = 4, 0.05
+    _, _, s1, _, _ = gpu_bh(nb, b, nsteps=k, dt=dt, ref_compat=1)
+    _, _, s2, _, _ = gpu_bh(nb, b, nsteps=k, dt=dt, ref_compat=2)
+    lim = n - n % 8
+    for f in ("velX", "velY"):
+        assert np.array_equal(s1[f][lim:], getattr(b, f)[lim:])  # tail velocities untouched in both
+        assert np.array_equal(s2[f][lim:], getattr(b, f)[lim:])
+    for f, v in (("posX", "velX"), ("posY", "velY")):
+        assert np.array_equal(s1[f][lim:], getattr(b, f)[lim:])  # benchmark.cpp: frozen
+        want = getattr(b, f)[lim:].astype(np.float64)
+        for _ in range(k):                                       # k fused multiply-adds in fp32
+            want = (want + getattr(b, v)[lim:].astype(np.float64) * np.float64(np.float32(dt))).astype(np.float32).astype(np.float64)
+        assert np.allclose(s2[f][lim:], want, rtol=2e-7, atol=0)
+        assert not np.array_equal(s2[f][lim:], getattr(b, f)[lim:])
+    if lim:
+        # the drifting tail bodies are sources in the tree, so from step 2 on the other bodies feel the difference
+        assert not np.array_equal(s1["posX"][:lim], s2["posX"][:lim])
+        c = b.copy()
+        O.bh_steps(c, 400.0, 1.0, dt, 1)                          # after ONE step the non-tail bodies still agree
+        _, _, one, _, _ = gpu_bh(nb, b, nsteps=1, dt=dt, ref_compat=2)
+        assert np.array_equal(one["posX"][:lim], c.posX[:lim]) and np.array_equal(one["velX"][:lim], c.velX[:lim])
