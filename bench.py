@@ -185,6 +185,9 @@ def main():
                          "note": "dependent-load tree walk: 24 B per group-visit (rank 0's launch), mostly L2-resident, "
                                  "so the HBM fraction is a floor, not a target; no flop convention (SURVEY.md §8d)"},
         }
+        if world == 1 and n == 1_000_000 and args.theta == 1.0 and not args.bh_fast_math:
+            line["roofline"]["traffic"] = 2 * 1358941.2 * 1024          # FETCH_SIZE KiB x2 (gfx950), per walk launch
+            line["roofline"]["traffic_source"] = "profiles/r1_bh_n1m_pmc_summary.csv (separate rocprofv3 --pmc passes; not live)"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_bh(n, args.theta)
         print(json.dumps(line), flush=True)
