@@ -46,10 +46,19 @@ def cpu_baseline(budget_s=12.0):
             r = O.ref_run(n, use_barnes_hut=0, nsteps=2, bodies=b)
             ms.extend(r["step_ms"].tolist())
         med = float(np.median(ms))
-        return dict(value=n * n / (med * 1e-3) / 1e9, unit="G interactions/s", cores=int(cores), kind="reference",
-                    sample=f"reference benchmark.cpp naive loop (OpenMP+AVX2, -O3 -ffast-math, x86-64-v3), N={n}, "
-                           f"median of {len(ms)} steps, {med:.1f} ms/step; rate is N-independent (compute-bound, "
-                           f"SURVEY.md §6.2) so N=2^20 would take ~{med * 256 / 1e3:.0f} s/step")
+        out = dict(value=n * n / (med * 1e-3) / 1e9, unit="G interactions/s", cores=int(cores), kind="reference",
+                   sample=f"reference benchmark.cpp naive loop (OpenMP+AVX2, -O3 -ffast-math, x86-64-v3), N={n}, "
+                          f"median of {len(ms)} steps, {med:.1f} ms/step; rate is N-independent (compute-bound, "
+                          f"SURVEY.md §6.2) so N=2^20 would take ~{med * 256 / 1e3:.0f} s/step")
+        try:                                   # SURVEY.md §8d also asks for the one-core figure
+            gomp = ctypes.CDLL("libgomp.so.1")
+            gomp.omp_set_num_threads(1)
+            one = O.ref_run(n, use_barnes_hut=0, nsteps=2, bodies=b)["step_ms"]
+            gomp.omp_set_num_threads(int(cores))
+            out["single_core_value"] = n * n / (float(np.median(one)) * 1e-3) / 1e9
+        except OSError:
+            pass
+        return out
     # no compiled reference on this box: time the plain-C restatement instead
     b = O.init_disc(16384, seed=12345)
     t0 = time.time()
