@@ -14,6 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(_HERE, "libnbody_oracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libnbody_ref.so")
+REF_DROPIN_SO = os.path.join(_HERE, "_ref", "libnbody_ref_dropin.so")   # same file, physics block -> include/nbody.h
 
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -200,10 +201,15 @@ class _RefIO(C.Structure):
 
 
 _ref = None
+_ref_dropin = None
 
 
 def ref_available():
     return os.path.exists(REF_SO)
+
+
+def ref_dropin_available():
+    return os.path.exists(REF_DROPIN_SO)
 
 
 def _fp(a):
@@ -211,16 +217,26 @@ def _fp(a):
 
 
 def ref_run(n, *, use_barnes_hut, nsteps, bodies=None, seed=12345, spread=400.0, mass=1000.0, theta=1.0,
-            dt=0.05, use_parallel=1, want_pool=False):
+            dt=0.05, use_parallel=1, want_pool=False, dropin=False):
     """Run the compiled reference loop (benchmark.cpp:349-557) for nsteps.
 
     bodies=None -> the reference's own generator (benchmark.cpp:317-339) with `seed`.
+    dropin=True -> the DROP-IN build: the same reference program with its physics block replaced by the C-ABI
+    (needs a GPU; tree read-back fields stay empty).
     Returns dict(init=Bodies, final=Bodies, acc=(ax, ay) of the last step, nodes_used, root, pool, step_ms)."""
-    global _ref
-    if _ref is None:
-        _ref = C.CDLL(REF_SO)
-        _ref.ref_benchmark_run.argtypes = [C.POINTER(_RefIO)]
-        _ref.ref_benchmark_run.restype = C.c_int
+    global _ref, _ref_dropin
+    if dropin:
+        if _ref_dropin is None:
+            _ref_dropin = C.CDLL(REF_DROPIN_SO)
+            _ref_dropin.ref_benchmark_run_dropin.argtypes = [C.POINTER(_RefIO)]
+            _ref_dropin.ref_benchmark_run_dropin.restype = C.c_int
+        entry = _ref_dropin.ref_benchmark_run_dropin
+    else:
+        if _ref is None:
+            _ref = C.CDLL(REF_SO)
+            _ref.ref_benchmark_run.argtypes = [C.POINTER(_RefIO)]
+            _ref.ref_benchmark_run.restype = C.c_int
+        entry = _ref.ref_benchmark_run
     io = _RefIO()
     io.use_barnes_hut, io.use_parallel, io.n = int(use_barnes_hut), int(use_parallel), n
     io.spread, io.mass, io.theta, io.dt = spread, mass, theta, dt
@@ -250,7 +266,7 @@ def ref_run(n, *, use_barnes_hut, nsteps, bodies=None, seed=12345, spread=400.0,
         io.tree_pool_cap = cap
     ms = np.zeros(max(nsteps, 1))
     io.step_ms = ms.ctypes.data_as(C.POINTER(C.c_double))
-    rc = _ref.ref_benchmark_run(C.byref(io))
+    rc = entry(C.byref(io))
     if rc != 0:
         raise RuntimeError(f"ref_benchmark_run returned {rc}")
     srcb = bodies if bodies is not None else init

@@ -60,3 +60,41 @@ END { if (bad) exit 3 }
 g++ -shared -fopenmp "$OUT_DIR/nbody_ref.o" -o "$OUT_DIR/libnbody_ref.so" -lpthread
 rm -f "$OUT_DIR/nbody_ref.o"
 echo "build_ref: built $OUT_DIR/libnbody_ref.so"
+
+# ---- drop-in build: the same file with INTEGRATION.md's edit applied (physics -> include/nbody.h on the GPU) ----
+# Same compiler flags as above, so that the generator and the harness are the same machine code in both builds.
+LIBDIR="$HERE/../n-body_amd/lib"
+if [ -f "$LIBDIR/libnbody_amd.so" ]; then
+awk '
+function expect(re) { if ($0 !~ re) { printf("build_ref(dropin): line %d does not match /%s/: %s\n", NR, re, $0) > "/dev/stderr"; bad = 1 } }
+NR==72  { expect("private:");                 print "public:"; next }
+NR==297 { expect("^int main\\(\\)");          print "extern \"C\" int ref_benchmark_run_dropin(RefIO *p)"; next }
+NR==300 { expect("bool useBarnesHut = true"); print "    bool useBarnesHut = p->use_barnes_hut != 0;"; next }
+NR==301 { expect("bool useParallel = true");  print "    bool useParallel = p->use_parallel != 0;"; next }
+NR==302 { expect("int n = 10000");            print "    int n = p->n;"; next }
+NR==303 { expect("float spread = 400");       print "    float spread = p->spread;"; next }
+NR==304 { expect("float mass = 1000");        print "    float mass = p->mass;"; next }
+NR==305 { expect("float theta = 1");          print "    float theta = p->theta;"; next }
+NR==306 { expect("float dt = 0.05");          print "    float dt = p->dt;"; next }
+NR==312 { expect("random_device");            print "    std::mt19937 rng(p->seed);"; next }
+NR==314 { expect("log.txt");                  print "    std::ofstream logFile(p->log_enabled ? \"log.txt\" : \"/dev/null\", std::ios::app);"; next }
+NR==339 { expect("^    }");                   print; print "    REF_AFTER_INIT(data);"; next }
+NR==341 { expect("QuadTree tree;");           print "    REF_DROPIN_CREATE(data)"; next }
+NR==342 { expect("tree.init\\(n, spread\\)");  next }
+NR==349 { expect("while \\(true\\)");         print "    for (int ref_step = 0; ref_step < p->nsteps; ++ref_step)"; next }
+NR==354 { expect("if \\(useBarnesHut\\)");    print "        REF_DROPIN_STEP();"; next }
+NR>354 && NR<511 { next }
+NR==511 { expect("^        }");               next }
+NR==513 { expect("physicsEnd = Clock::now");  print; print "        REF_STEP_TIME(physicsStart, physicsEnd);"; next }
+NR==534 { expect("elapsedTime >= logInterval"); print "        if (p->log_enabled && elapsedTime >= logInterval)"; next }
+NR==559 { expect("logFile.is_open");          print "    REF_DROPIN_FINISH(data);"; print "    REF_AFTER_LOOP(data);"; print; next }
+{ print }
+END { if (bad) exit 3 }
+' "$REF_SRC" | g++ -std=c++17 -O3 -march=x86-64-v3 -ffast-math -mavx2 -mfma -fopenmp -DNDEBUG \
+    -fPIC -c -include "$HERE/dropin_hooks.h" -x c++ - -o "$OUT_DIR/nbody_ref_dropin.o"
+g++ -shared -fopenmp "$OUT_DIR/nbody_ref_dropin.o" -o "$OUT_DIR/libnbody_ref_dropin.so" -L"$LIBDIR" -lnbody_amd \
+    -Wl,-rpath,'$ORIGIN/../../n-body_amd/lib' -lpthread
+rm -f "$OUT_DIR/nbody_ref_dropin.o"
+echo "build_ref: built $OUT_DIR/libnbody_ref_dropin.so (reference harness + GPU physics)"
+fi
+
