@@ -78,14 +78,22 @@ __device__ __forceinline__ int bh_lcp_levels(uint64_t a, uint64_t b)
 }
 
 // 1. path keys ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bh_reset_counters(BhCounters* __restrict__ ctr, float root_half0);
+
+// fixed_box != 0 (the reference's root box): the half-width comes by value and thread 0 also resets the counters of
+// this build (a separate 1-thread launch otherwise; every launch of a short kernel costs ~4.5 us here).  Every
+// launch also pre-fills the tie-instance buffer with padding that sorts last (bh_ties_kernel overwrites the front).
 __global__ __launch_bounds__(kBhBlock) void bh_keys_kernel(const float* __restrict__ px, const float* __restrict__ py,
-                                                           int n, const BhCounters* __restrict__ ctr,
-                                                           uint64_t* __restrict__ keys, int* __restrict__ vals,
-                                                           uint16_t* __restrict__ tie)
+                                                           int n, BhCounters* __restrict__ ctr, float spread_fixed,
+                                                           int fixed_box, uint64_t* __restrict__ keys,
+                                                           int* __restrict__ vals, uint16_t* __restrict__ tie,
+                                                           uint64_t* __restrict__ gkeys, int* __restrict__ gvals, int gcap)
 {
     const int i = blockIdx.x * kBhBlock + threadIdx.x;
+    for (int g = i; g < gcap; g += gridDim.x * kBhBlock) { gkeys[g] = ~0ull; gvals[g] = -1; }
+    if (fixed_box && i == 0) bh_reset_counters(ctr, spread_fixed);
     if (i >= n) return;
-    const float spread = ctr->root_half;
+    const float spread = fixed_box ? spread_fixed : ctr->root_half;
     const float x = px[i], y = py[i];
     float tlx = -spread, tly = -spread, brx = spread, bry = spread;
     uint64_t key;
@@ -123,9 +131,8 @@ __global__ void bh_valid_kernel(const uint64_t* __restrict__ keys, int n, BhCoun
 }
 
 // root_half0: the fixed box (spread), or a tiny positive floor that bh_bounds_kernel raises (adaptive box)
-__global__ void bh_reset_kernel(BhCounters* __restrict__ ctr, float root_half0)
+__device__ __forceinline__ void bh_reset_counters(BhCounters* __restrict__ ctr, float root_half0)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     ctr->root_half = root_half0;
     ctr->valid = 0;
     ctr->internal = 0;
@@ -134,6 +141,12 @@ __global__ void bh_reset_kernel(BhCounters* __restrict__ ctr, float root_half0)
     ctr->visits = 0;
     ctr->accepts = 0;
     ctr->wave_iters = 0;
+}
+
+__global__ void bh_reset_kernel(BhCounters* __restrict__ ctr, float root_half0)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    bh_reset_counters(ctr, root_half0);
 }
 
 // Adaptive root box (opt-in, nbody_config.adaptive_box): h = max_i max(|x_i|,|y_i|) over finite positions.
@@ -214,22 +227,16 @@ __global__ __launch_bounds__(kBhBlock) void bh_ties_kernel(const uint64_t* __res
     }
 }
 
-// pad the unused tail of the instance buffer with keys that sort after everything else
-__global__ __launch_bounds__(kBhBlock) void bh_ghost_pad_kernel(const BhCounters* __restrict__ ctr, uint64_t* __restrict__ gkeys,
-                                                                int* __restrict__ gvals, int gcap)
-{
-    const int g = blockIdx.x * kBhBlock + threadIdx.x;
-    if (g >= gcap) return;
-    const int G = ctr->ghosts < gcap ? ctr->ghosts : gcap;
-    if (g >= G) { gkeys[g] = ~0ull; gvals[g] = -1; }
-}
-
 // merge sorted primaries [n] and sorted second instances [gcap] into one sorted array [n + gcap]
 __global__ __launch_bounds__(kBhBlock) void bh_merge_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals, int n,
                                                             const uint64_t* __restrict__ gkeys, const int* __restrict__ gvals,
-                                                            int gcap, uint64_t* __restrict__ okeys, int* __restrict__ ovals)
+                                                            int gcap, uint64_t* __restrict__ okeys, int* __restrict__ ovals,
+                                                            BhCounters* __restrict__ ctr)
 {
     const int t = blockIdx.x * kBhBlock + threadIdx.x;
+    // valid INSTANCES of the merged array = valid primaries + second instances (their keys have bit 63 clear, the
+    // padding and the out-of-box bodies have it set and sort behind them); nobody else in this launch reads ctr
+    if (t == 0) ctr->valid += ctr->ghosts < gcap ? ctr->ghosts : gcap;
     if (t < n) {
         const uint64_t k = keys[t];
         int lo = 0, hi = gcap;                                 // second instances with a smaller key
@@ -466,11 +473,15 @@ __global__ __launch_bounds__(kBhComBlock) void bh_com_small_kernel(BhTree t, con
 struct BhWalkArgs {
     const float4* __restrict__ A;
     const int2* __restrict__ B;
-    const float* __restrict__ px;
-    const float* __restrict__ py;
+    float* px;                       // read at the start of the walk, written at its end when advance != 0:
+    float* py;                       // deliberately neither const nor __restrict__
     const float* __restrict__ radius;
-    float* __restrict__ ax;          // [i_stride] row 0 of the partial buffer, indexed i - i_begin
+    float* __restrict__ vx;
+    float* __restrict__ vy;
+    float* __restrict__ ax;          // total accelerations [n], indexed by body
     float* __restrict__ ay;
+    float dt;
+    int advance;                     // 1: forward Euler on the walked bodies (benchmark.cpp:382-401), 0: forces only
     BhCounters* __restrict__ ctr;
     int i_begin, i_end;              // targets; i_begin is a multiple of 8
     float theta;
@@ -587,7 +598,20 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
             }
         }
     }
-    if (live) { w.ax[i - w.i_begin] = ax; w.ay[i - w.i_begin] = ay; }
+    // The reference integrates each group right after its walk, in place (benchmark.cpp:382-401): that is race-free
+    // because the tree holds COPIES of the positions (leaf records), and it is race-free here for the same reason —
+    // during the walk a lane reads posX/posY of its own body only, once, above.
+    if (live) {
+        w.ax[i] = ax;
+        w.ay[i] = ay;
+        if (w.advance) {
+            const float u = w.vx[i], v = w.vy[i];
+            w.px[i] = __builtin_fmaf(u, w.dt, xi);          // :389-390 from the OLD velocity
+            w.py[i] = __builtin_fmaf(v, w.dt, yi);
+            w.vx[i] = __builtin_fmaf(ax, w.dt, u);          // :393-394
+            w.vy[i] = __builtin_fmaf(ay, w.dt, v);
+        }
+    }
 
     // counters: one representative lane per group
     unsigned long long v = (tid & 7) == 0 ? visits : 0, acc = (tid & 7) == 0 ? accepts : 0;

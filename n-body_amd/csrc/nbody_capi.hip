@@ -202,6 +202,7 @@ int enqueue_integrate(nbody_ctx* ctx, int advance)
         tail_drift_kernel<<<1, 8, 0, ctx->stream>>>(ctx->px, ctx->py, ctx->vx, ctx->vy, n - tail, n, ctx->cfg.dt);
         HIP_TRY(hipGetLastError());
     }
+    if (ctx->cfg.use_barnes_hut) return NBODY_OK;     // the walk kernel has stored the accelerations and integrated
     if (ctx->i_end <= ctx->i_begin) return NBODY_OK;
     IntegrateArgs a{};
     a.px = ctx->px; a.py = ctx->py; a.vx = ctx->vx; a.vy = ctx->vy;
@@ -230,22 +231,23 @@ int enqueue_bh_build(nbody_ctx* ctx)
     int rc = profile_begin(ctx, 2, &ep);
     if (rc) return rc;
     const int nm = n + b.gcap;                                 // instances after the merge (tail = padding)
-    const dim3 grid_g((b.gcap + kBhBlock - 1) / kBhBlock), grid_m((nm + kBhBlock - 1) / kBhBlock);
+    const dim3 grid_m((nm + kBhBlock - 1) / kBhBlock);
     const bool adaptive = ctx->cfg.adaptive_box != 0;
-    bh_reset_kernel<<<1, 64, 0, s>>>(b.ctr, adaptive ? 1e-30f : ctx->cfg.spread);
-    if (adaptive) bh_bounds_kernel<<<dim3(grid_n.x < 1024u ? grid_n.x : 1024u), blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr);
-    bh_keys_kernel<<<grid_n, blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr, b.keys, b.vals, b.tie);
+    if (adaptive) {
+        bh_reset_kernel<<<1, 64, 0, s>>>(b.ctr, 1e-30f);
+        bh_bounds_kernel<<<dim3(grid_n.x < 1024u ? grid_n.x : 1024u), blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr);
+    }
+    bh_keys_kernel<<<grid_n, blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr, ctx->cfg.spread, adaptive ? 0 : 1, b.keys, b.vals, b.tie,
+                                          b.gkeys, b.gvals, b.gcap);
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, b.keys, b.keys_sorted, b.vals, b.vals_sorted, n,
                                                0, 64, s));
     bh_valid_kernel<<<1, 64, 0, s>>>(b.keys_sorted, n, b.ctr);
     // bodies exactly on a split line get a second instance (inclusive bounds, benchmark.cpp:83-85)
     bh_ties_kernel<<<grid_n, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, b.gkeys, b.gvals, b.gcap);
-    bh_ghost_pad_kernel<<<grid_g, blk, 0, s>>>(b.ctr, b.gkeys, b.gvals, b.gcap);
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.gsort_tmp, b.gsort_bytes, b.gkeys, b.gkeys_sorted, b.gvals, b.gvals_sorted,
                                                b.gcap, 0, 64, s));
     bh_merge_kernel<<<grid_m, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, n, b.gkeys_sorted, b.gvals_sorted, b.gcap,
-                                           b.keys_merged, b.vals_merged);
-    bh_valid_kernel<<<1, 64, 0, s>>>(b.keys_merged, nm, b.ctr);
+                                           b.keys_merged, b.vals_merged, b.ctr);
     bh_count_kernel<<<grid_m, blk, 0, s>>>(b.keys_merged, nm, b.ctr, b.cnt);
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b.scan_tmp, b.scan_bytes, b.cnt, b.base, nm, s));
     const dim3 grid_c((b.tree.cap_internal + kBhBlock - 1) / kBhBlock);
@@ -267,13 +269,16 @@ int enqueue_bh_build(nbody_ctx* ctx)
     return profile_end(ctx, 2, ep);
 }
 
-int enqueue_bh_walk(nbody_ctx* ctx)
+// walk + (advance) the Euler update of the walked bodies, fused as in the reference (benchmark.cpp:365-401)
+int enqueue_bh_walk(nbody_ctx* ctx, int advance)
 {
     if (ctx->i_end <= ctx->i_begin) return NBODY_OK;
     BhWalkArgs w{};
     w.A = ctx->bh.tree.A; w.B = ctx->bh.tree.B;
     w.px = ctx->px; w.py = ctx->py; w.radius = ctx->radius;
-    w.ax = ctx->pax; w.ay = ctx->pay; w.ctr = ctx->bh.ctr;
+    w.vx = ctx->vx; w.vy = ctx->vy;
+    w.ax = ctx->ax; w.ay = ctx->ay; w.ctr = ctx->bh.ctr;
+    w.dt = ctx->cfg.dt; w.advance = advance;
     w.i_begin = ctx->i_begin; w.i_end = ctx->i_end; w.theta = ctx->cfg.theta;
     const int nt = ctx->i_end - ctx->i_begin;
     EventPair* ep;
@@ -645,7 +650,7 @@ int enqueue_one_step(nbody_ctx* ctx)
             rc = enqueue_bh_build(ctx);                      // benchmark.cpp:357
             if (rc) return rc;
             if (!ctx->cfg.use_parallel) return NBODY_OK;     // benchmark.cpp:359: tree built, nothing else happens
-            rc = enqueue_bh_walk(ctx);                       // :365-380
+            rc = enqueue_bh_walk(ctx, 1);                    // :365-401
         } else {
             rc = enqueue_force(ctx);                         // :407-478
         }
@@ -666,7 +671,7 @@ int nbody_compute_accel(nbody_ctx* ctx)
     if (ctx->cfg.use_barnes_hut) {
         rc = enqueue_bh_build(ctx);
         if (rc) return rc;
-        rc = enqueue_bh_walk(ctx);
+        rc = enqueue_bh_walk(ctx, 0);
     } else {
         rc = enqueue_force(ctx);
     }
