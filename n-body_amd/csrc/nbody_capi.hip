@@ -720,12 +720,13 @@ int nbody_frame_publish(nbody_ctx* ctx)
     constexpr int kSlots = nbody_ctx::Frames::kSlots;
     const size_t nb = sizeof(float) * (size_t)ctx->cfg.num_bodies;
     if (!f.ready) {
-        HIP_TRY(hipStreamCreateWithFlags(&f.copy_stream, hipStreamNonBlocking));
+        // (re-entrant after a failed attempt: only what is still missing is created; nbody_destroy frees the rest)
+        if (!f.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&f.copy_stream, hipStreamNonBlocking));
         for (int k = 0; k < kSlots; ++k) {
-            HIP_TRY(hipMalloc((void**)&f.dev[k], 2 * nb));
-            HIP_TRY(hipHostMalloc((void**)&f.host[k], 2 * nb, hipHostMallocDefault));
-            HIP_TRY(hipEventCreateWithFlags(&f.snapped[k], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&f.landed[k], hipEventDisableTiming));
+            if (!f.dev[k]) HIP_TRY(hipMalloc((void**)&f.dev[k], 2 * nb));
+            if (!f.host[k]) HIP_TRY(hipHostMalloc((void**)&f.host[k], 2 * nb, hipHostMallocDefault));
+            if (!f.snapped[k]) HIP_TRY(hipEventCreateWithFlags(&f.snapped[k], hipEventDisableTiming));
+            if (!f.landed[k]) HIP_TRY(hipEventCreateWithFlags(&f.landed[k], hipEventDisableTiming));
         }
         f.ready = true;
     }
