@@ -87,10 +87,12 @@ __global__ __launch_bounds__(kBhBlock) void bh_keys_kernel(const float* __restri
                                                            int n, BhCounters* __restrict__ ctr, float spread_fixed,
                                                            int fixed_box, uint64_t* __restrict__ keys,
                                                            int* __restrict__ vals, uint16_t* __restrict__ tie,
-                                                           uint64_t* __restrict__ gkeys, int* __restrict__ gvals, int gcap)
+                                                           uint64_t* __restrict__ gkeys, int* __restrict__ gvals, int gcap,
+                                                           int* __restrict__ tie_table, int tie_table_size)
 {
     const int i = blockIdx.x * kBhBlock + threadIdx.x;
     for (int g = i; g < gcap; g += gridDim.x * kBhBlock) { gkeys[g] = ~0ull; gvals[g] = -1; }
+    for (int g = i; g < tie_table_size; g += gridDim.x * kBhBlock) tie_table[g] = -1;
     if (fixed_box && i == 0) bh_reset_counters(ctr, spread_fixed);
     if (i >= n) return;
     const float spread = fixed_box ? spread_fixed : ctr->root_half;
@@ -171,59 +173,183 @@ __global__ __launch_bounds__(kBhBlock) void bh_bounds_kernel(const float* __rest
     }
 }
 
-// One descent with the reference's float arithmetic.  force_level/force_axis: take the UPPER child on that axis
-// at that level regardless of the comparison (the second instance of a body sitting exactly on the split line).
-// Returns the key; reports the first level at which x (resp. y) equals the midpoint, or kBhLevels.
-__device__ __forceinline__ uint64_t bh_descend(float x, float y, float spread, int fx_level, int fy_level, int* tie_x,
-                                               int* tie_y)
+// One descent with the reference's float arithmetic.  fx/fy: bit l set = take the UPPER child on that axis at level
+// l regardless of the comparison (an instance that went "up" at a split line the body sits on).  Returns the key
+// and, per axis, the mask of the levels at which the coordinate equals the midpoint WITHOUT being forced there,
+// i.e. the split lines this instance sits on and went "down" at.
+__device__ __forceinline__ uint64_t bh_descend(float x, float y, float spread, unsigned fx, unsigned fy, unsigned* tie_x,
+                                               unsigned* tie_y)
 {
     float tlx = -spread, tly = -spread, brx = spread, bry = spread;
     uint64_t key = 0;
-    int tx = kBhLevels, ty = kBhLevels;
+    unsigned tx = 0, ty = 0;
 #pragma unroll 1
     for (int l = 0; l < kBhLevels; ++l) {
         const float mx = (tlx + brx) / 2.0f, my = (tly + bry) / 2.0f;    // benchmark.cpp:98-99
-        if (x == mx && tx == kBhLevels) tx = l;
-        if (y == my && ty == kBhLevels) ty = l;
-        const int qx = (x > mx) || l == fx_level, qy = (y > my) || l == fy_level;   // on the line -> lower child
+        const bool ux = (fx >> l) & 1u, uy = (fy >> l) & 1u;
+        if (x == mx && !ux) tx |= 1u << l;
+        if (y == my && !uy) ty |= 1u << l;
+        const int qx = (x > mx) || ux, qy = (y > my) || uy;               // on the line -> lower child
         key = (key << 2) | (uint64_t)(qy * 2 + qx);                      // TL, TR, BL, BR (benchmark.cpp:105-108)
         tlx = qx ? mx : tlx; brx = qx ? brx : mx;
         tly = qy ? my : tly; bry = qy ? bry : my;
     }
-    if (tie_x) *tie_x = tx;
-    if (tie_y) *tie_y = ty;
+    *tie_x = tx;
+    *tie_y = ty;
     return key;
 }
 
-// 2b. second instances.  Runs on the sorted primaries; leaf depth of body i = 1 + max(lcp with its neighbours).
+// 2b. second instances.  A body exactly ON the split line of an INTERNAL cell is in both children (inclusive bounds,
+// benchmark.cpp:83-85), and each of those instances can sit on further split lines below.  The instances of a body
+// form a little tree: instance I spawns "I, but up at level t on axis a" for every unforced tie (a, t) of its own
+// path whose cell is internal, i.e. t < leaf depth of I = 1 + the longest common prefix of I's key with the key of
+// any instance of ANOTHER body.  Forced levels are only ever added in increasing (level, axis) order, so every
+// combination has exactly one parent.  Because a second instance can turn the leaf it lands in into an internal
+// cell — and so switch on a tie of the body that lived there — the set is a least fixed point:
+//   bh_ties_kernel          one thread per sorted primary, depth-first over its instances, leaf depths taken
+//                           against the PRIMARIES only (the whole answer for all but contrived inputs);
+//   bh_tie_fixpoint_kernel  one workgroup, rounds until nothing is added: every instance added in the previous
+//                           round raises the known leaf depth of itself and of its neighbours (atomicMax: whoever
+//                           raises it from a to b spawns the ties in [a, b), so nothing is spawned twice).
+struct BhTies {
+    uint64_t* __restrict__ gkeys;        // [gcap] second instances, unsorted
+    int* __restrict__ gvals;             // body of each
+    unsigned* __restrict__ gfx;          // forced-up levels of each, per axis
+    unsigned* __restrict__ gfy;
+    int* __restrict__ gld;               // leaf depth up to which its ties have been expanded
+    int* __restrict__ glo;               // its neighbours among the sorted primaries (own primary skipped): indices,
+    int* __restrict__ ghi;               //   -1 / M when there is none
+    int* __restrict__ gpos;              // its insertion position among the sorted primaries
+    int* __restrict__ pld;               // leaf depth up to which the ties of body b's PRIMARY have been expanded
+    int* __restrict__ table;             // open-addressing hash: insertion position -> instance index (-1 = empty);
+    int table_mask;                      //   cleared by bh_keys_kernel, size = table_mask + 1 >= 2 * gcap
+    int gcap;
+};
+
+__device__ __forceinline__ int bh_tie_hash(int pos, int mask) { return (int)(((unsigned)pos * 2654435761u) >> 7) & mask; }
+
+__device__ __forceinline__ int bh_lower_bound(const uint64_t* __restrict__ keys, int lo, int hi, uint64_t v);
+
+// ties of instance (x, y, fx, fy) at levels [from, to): append the spawned instances.  first_tie: lowest level at
+// which the instance can have a tie at all, when the caller knows it (saves the descent in the common case).
+__device__ __forceinline__ void bh_spawn_ties(float x, float y, float spread, unsigned fx, unsigned fy, int from, int to, int body,
+                                              int first_tie, const uint64_t* __restrict__ keys, const int* __restrict__ vals,
+                                              int M, const BhTies& T, BhCounters* __restrict__ ctr)
+{
+    if (to > kBhLevels) to = kBhLevels;
+    if (from >= to || first_tie >= to) return;
+    unsigned tx, ty;
+    (void)bh_descend(x, y, spread, fx, fy, &tx, &ty);
+    const unsigned forced = fx | fy;
+    const int last = forced ? 31 - __builtin_clz(forced) : -1;
+    const bool last_is_y = last >= 0 && ((fy >> last) & 1u);
+    for (int t = from > last ? from : (last < 0 ? 0 : last); t < to; ++t) {
+        const bool x_ok = ((tx >> t) & 1u) && t > last;                            // (level, axis) order: x before y
+        const bool y_ok = ((ty >> t) & 1u) && (t > last || (t == last && !last_is_y));
+        for (int a = 0; a < 2; ++a) {
+            if (!(a == 0 ? x_ok : y_ok)) continue;
+            const unsigned nfx = a == 0 ? fx | (1u << t) : fx, nfy = a == 1 ? fy | (1u << t) : fy;
+            unsigned ux, uy;
+            const uint64_t k = bh_descend(x, y, spread, nfx, nfy, &ux, &uy);
+            const int pos = bh_lower_bound(keys, 0, M, k);
+            int lo = pos - 1, hi = pos;
+            if (lo >= 0 && vals[lo] == body) --lo;
+            if (hi < M && vals[hi] == body) ++hi;
+            const int slot = atomicAdd(&ctr->ghosts, 1);
+            if (slot < T.gcap) {
+                T.gkeys[slot] = k; T.gvals[slot] = body; T.gfx[slot] = nfx; T.gfy[slot] = nfy; T.gld[slot] = 0;
+                T.glo[slot] = lo; T.ghi[slot] = hi; T.gpos[slot] = pos;
+                __threadfence();                                 // the record before its index becomes findable
+                int hs = bh_tie_hash(pos, T.table_mask);
+                while (atomicCAS(&T.table[hs], -1, slot) != -1) hs = (hs + 1) & T.table_mask;
+            } else {
+                ctr->overflow = 2;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int bh_first_tie(uint16_t rec)
+{
+    const int tx = rec & 0xFF, ty = rec >> 8;
+    return tx < ty ? tx : ty;                                    // kBhLevels when the primary's path has none
+}
+
 __global__ __launch_bounds__(kBhBlock) void bh_ties_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
                                                            const float* __restrict__ px, const float* __restrict__ py,
                                                            const uint16_t* __restrict__ tie, BhCounters* __restrict__ ctr,
-                                                           uint64_t* __restrict__ gkeys, int* __restrict__ gvals, int gcap)
+                                                           BhTies T)
 {
     const int i = blockIdx.x * kBhBlock + threadIdx.x;
     const int M = ctr->valid;
     if (i >= M) return;
     const int b = vals[i];
-    const int tx = tie[b] & 0xFF, ty = tie[b] >> 8;           // recorded by bh_keys_kernel
-    if (tx == kBhLevels && ty == kBhLevels) return;           // all but a few hundred per million
-    const float spread = ctr->root_half;
+    const int first = bh_first_tie(tie[b]);
+    if (first == kBhLevels) return;                              // no split line on the primary's path:
+                                                                 // all but a few hundred per million
     const uint64_t k = keys[i];
     const int lp = i > 0 ? bh_lcp_levels(keys[i - 1], k) : -1;
     const int ln = i + 1 < M ? bh_lcp_levels(k, keys[i + 1]) : -1;
-    const int leaf_depth = 1 + (lp > ln ? lp : ln);           // 0 when the body is alone in the tree
-    const float x = px[b], y = py[b];
-    const bool ax_on = tx < leaf_depth, ay_on = ty < leaf_depth;   // the cell where the tie happens is internal
-    if (!ax_on && !ay_on) return;
-    uint64_t out[3];
-    int cnt = 0;
-    if (ax_on) out[cnt++] = bh_descend(x, y, spread, tx, -1, nullptr, nullptr);
-    if (ay_on) out[cnt++] = bh_descend(x, y, spread, -1, ty, nullptr, nullptr);
-    if (ax_on && ay_on) out[cnt++] = bh_descend(x, y, spread, tx, ty, nullptr, nullptr);
-    const int slot = atomicAdd(&ctr->ghosts, cnt);             // a few hundred per million bodies
-    for (int q = 0; q < cnt; ++q) {
-        if (slot + q < gcap) { gkeys[slot + q] = out[q]; gvals[slot + q] = b; }
-        else ctr->overflow = 2;
+    const int leaf_depth = 1 + (lp > ln ? lp : ln);              // 0 when the body is alone in the tree
+    T.pld[b] = leaf_depth;
+    bh_spawn_ties(px[b], py[b], ctr->root_half, 0u, 0u, 0, leaf_depth, b, first, keys, vals, M, T, ctr);
+}
+
+constexpr int kBhFixBlock = 1024;
+__global__ __launch_bounds__(kBhFixBlock) void bh_tie_fixpoint_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
+                                                                      const float* __restrict__ px, const float* __restrict__ py,
+                                                                      const uint16_t* __restrict__ tie, BhCounters* __restrict__ ctr,
+                                                                      BhTies T)
+{
+    __shared__ int s_end;
+    const int M = ctr->valid;
+    const float spread = ctr->root_half;
+    int begin = 0;
+    if (threadIdx.x == 0) { const int g = __hip_atomic_load(&ctr->ghosts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_end = g < T.gcap ? g : T.gcap; }
+    __syncthreads();
+    int end = s_end;
+    while (begin < end) {                                        // block-uniform; ends when a round adds nothing
+        for (int g = begin + (int)threadIdx.x; g < end; g += kBhFixBlock) {
+            const uint64_t k = T.gkeys[g];
+            const int b = T.gvals[g];
+            const int lo = T.glo[g], hi = T.ghi[g];
+            int ld = 0;
+            // neighbours among the primaries: this instance deepens their leaves
+            for (int side = 0; side < 2; ++side) {
+                const int j = side ? hi : lo;
+                if (j < 0 || j >= M) continue;
+                const int d = 1 + bh_lcp_levels(keys[j], k);
+                ld = d > ld ? d : ld;
+                const int bj = vals[j];
+                const int first = bh_first_tie(tie[bj]);
+                if (first < d) {
+                    const int old = atomicMax(&T.pld[bj], d);
+                    if (d > old) bh_spawn_ties(px[bj], py[bj], spread, 0u, 0u, old, d, bj, first, keys, vals, M, T, ctr);
+                }
+            }
+            // other bodies' second instances between the same primaries (lo, hi]: at most three insertion positions,
+            // looked up in the hash; instances added during this round (index >= end) wait for the next one
+            for (int ph = lo + 1; ph <= hi; ++ph) {
+                for (int hs = bh_tie_hash(ph, T.table_mask);; hs = (hs + 1) & T.table_mask) {
+                    const int h = __hip_atomic_load(&T.table[hs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (h < 0) break;
+                    if (h >= end || T.gpos[h] != ph) continue;
+                    const int bh_ = T.gvals[h];
+                    if (bh_ == b) continue;
+                    const int d = 1 + bh_lcp_levels(T.gkeys[h], k);
+                    ld = d > ld ? d : ld;
+                    const int old = atomicMax(&T.gld[h], d);
+                    if (d > old) bh_spawn_ties(px[bh_], py[bh_], spread, T.gfx[h], T.gfy[h], old, d, bh_, 0, keys, vals, M, T, ctr);
+                }
+            }
+            const int old = atomicMax(&T.gld[g], ld);
+            if (ld > old) bh_spawn_ties(px[b], py[b], spread, T.gfx[g], T.gfy[g], old, ld, b, 0, keys, vals, M, T, ctr);
+        }
+        __syncthreads();
+        begin = end;
+        if (threadIdx.x == 0) { const int g = __hip_atomic_load(&ctr->ghosts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_end = g < T.gcap ? g : T.gcap; }
+        __syncthreads();
+        end = s_end;
     }
 }
 

@@ -101,7 +101,10 @@ struct nbody_ctx {
         int *vals = nullptr, *vals_sorted = nullptr, *gvals = nullptr, *gvals_sorted = nullptr, *vals_merged = nullptr;
         int *cnt = nullptr, *base = nullptr;
         int* owner = nullptr;            // per internal cell: the sorted instance that owns it
-        uint16_t* tie = nullptr;         // per body: first levels at which x / y sit on a split line
+        uint16_t* tie = nullptr;
+        unsigned *gfx = nullptr, *gfy = nullptr;   // second instances: forced-up levels, expanded leaf depth
+        int *gld = nullptr, *pld = nullptr, *glo = nullptr, *ghi = nullptr, *gpos = nullptr, *tie_table = nullptr;
+        int tie_table_size = 0;         // per body: first levels at which x / y sit on a split line
         int gcap = 0;                    // capacity for second instances of bodies on split lines
         void* gsort_tmp = nullptr;
         size_t gsort_bytes = 0;
@@ -238,12 +241,14 @@ int enqueue_bh_build(nbody_ctx* ctx)
         bh_bounds_kernel<<<dim3(grid_n.x < 1024u ? grid_n.x : 1024u), blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr);
     }
     bh_keys_kernel<<<grid_n, blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr, ctx->cfg.spread, adaptive ? 0 : 1, b.keys, b.vals, b.tie,
-                                          b.gkeys, b.gvals, b.gcap);
+                                          b.gkeys, b.gvals, b.gcap, b.tie_table, b.tie_table_size);
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, b.keys, b.keys_sorted, b.vals, b.vals_sorted, n,
                                                0, 64, s));
     bh_valid_kernel<<<1, 64, 0, s>>>(b.keys_sorted, n, b.ctr);
     // bodies exactly on a split line get a second instance (inclusive bounds, benchmark.cpp:83-85)
-    bh_ties_kernel<<<grid_n, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, b.gkeys, b.gvals, b.gcap);
+    BhTies ties{b.gkeys, b.gvals, b.gfx, b.gfy, b.gld, b.glo, b.ghi, b.gpos, b.pld, b.tie_table, b.tie_table_size - 1, b.gcap};
+    bh_ties_kernel<<<grid_n, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties);
+    bh_tie_fixpoint_kernel<<<1, kBhFixBlock, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties);
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.gsort_tmp, b.gsort_bytes, b.gkeys, b.gkeys_sorted, b.gvals, b.gvals_sorted,
                                                b.gcap, 0, 64, s));
     bh_merge_kernel<<<grid_m, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, n, b.gkeys_sorted, b.gvals_sorted, b.gcap,
@@ -432,6 +437,16 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
         HIP_TRY_C(hipMalloc((void**)&b.gkeys_sorted, sizeof(uint64_t) * (size_t)b.gcap));
         HIP_TRY_C(hipMalloc((void**)&b.gvals, sizeof(int) * (size_t)b.gcap));
         HIP_TRY_C(hipMalloc((void**)&b.gvals_sorted, sizeof(int) * (size_t)b.gcap));
+        HIP_TRY_C(hipMalloc((void**)&b.gfx, sizeof(unsigned) * (size_t)b.gcap));
+        HIP_TRY_C(hipMalloc((void**)&b.gfy, sizeof(unsigned) * (size_t)b.gcap));
+        HIP_TRY_C(hipMalloc((void**)&b.gld, sizeof(int) * (size_t)b.gcap));
+        HIP_TRY_C(hipMalloc((void**)&b.glo, sizeof(int) * (size_t)b.gcap));
+        HIP_TRY_C(hipMalloc((void**)&b.ghi, sizeof(int) * (size_t)b.gcap));
+        HIP_TRY_C(hipMalloc((void**)&b.gpos, sizeof(int) * (size_t)b.gcap));
+        b.tie_table_size = 1;
+        while (b.tie_table_size < 2 * b.gcap) b.tie_table_size <<= 1;
+        HIP_TRY_C(hipMalloc((void**)&b.tie_table, sizeof(int) * (size_t)b.tie_table_size));
+        HIP_TRY_C(hipMalloc((void**)&b.pld, sizeof(int) * (size_t)n));
         HIP_TRY_C(hipMalloc((void**)&b.keys_merged, sizeof(uint64_t) * nm));
         HIP_TRY_C(hipMalloc((void**)&b.vals_merged, sizeof(int) * nm));
         HIP_TRY_C(hipMalloc((void**)&b.cnt, sizeof(int) * nm));
@@ -469,7 +484,7 @@ void nbody_destroy(nbody_ctx* ctx)
     {
         auto& b = ctx->bh;
         void* ptrs[] = {b.keys, b.keys_sorted, b.vals, b.vals_sorted, b.cnt, b.base, b.tree.A, b.tree.B,
-                        b.tree.depth, b.tree.self, b.ctr, b.tie, b.owner, b.sort_tmp, b.scan_tmp, b.gkeys, b.gkeys_sorted, b.gvals,
+                        b.tree.depth, b.tree.self, b.ctr, b.tie, b.owner, b.gfx, b.gfy, b.gld, b.pld, b.glo, b.ghi, b.gpos, b.tie_table, b.sort_tmp, b.scan_tmp, b.gkeys, b.gkeys_sorted, b.gvals,
                         b.gvals_sorted, b.keys_merged, b.vals_merged, b.gsort_tmp};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -893,8 +908,10 @@ int nbody_bh_counters(nbody_ctx* ctx, int64_t out[2])
     out[0] = (int64_t)h.visits;
     out[1] = (int64_t)h.accepts;
     if (std::getenv("NBODY_DEBUG"))
-        std::fprintf(stderr, "[nbody] walk: %llu group-visits in %llu wave iterations: %.1f %% of the 8 group slots busy\n",
-                     h.visits, h.wave_iters, h.wave_iters ? 100.0 * (double)h.visits / (8.0 * (double)h.wave_iters) : 0.0);
+        std::fprintf(stderr, "[nbody] walk: %llu group-visits in %llu wave iterations: %.1f %% of the 8 group slots busy; "
+                             "%d second instances (bodies on split lines), %d valid instances, %d internal cells\n",
+                     h.visits, h.wave_iters, h.wave_iters ? 100.0 * (double)h.visits / (8.0 * (double)h.wave_iters) : 0.0,
+                     h.ghosts, h.valid, h.internal);
     return NBODY_OK;
 }
 

@@ -342,3 +342,32 @@ def test_ref_compat_2_is_main_cpp_tail_bodies_drift_force_free(nb, O, n):
         O.bh_steps(c, 400.0, 1.0, dt, 1)                          # after ONE step the non-tail bodies still agree
         _, _, one, _, _ = gpu_bh(nb, b, nsteps=1, dt=dt, ref_compat=2)
         assert np.array_equal(one["posX"][:lim], c.posX[:lim]) and np.array_equal(one["velX"][:lim], c.velX[:lim])
+
+
+def test_randomized_adversarial_inputs_equal_the_oracle(nb, O):
+    """tools/bh_stress.py as a regression test: lattices whose points all lie ON split lines (second instances that
+    make further second instances necessary: the least fixed point computed by bh_tie_fixpoint_kernel), bodies on the
+    root axes, tight clusters, bodies outside the box, n from 1 to 4097, theta from 0.3 to 1.5 — node count, counters
+    and accelerations equal the oracle's bit for bit in every round."""
+    import importlib.util, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bh_stress.py")
+    spec = importlib.util.spec_from_file_location("bh_stress", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(2024)
+    checked = 0
+    for r in range(40):
+        kind = ["lattice", "cluster", "wide", "axis", "disc"][r % 5]
+        n = int(rng.choice([1, 2, 7, 8, 9, 63, 100, 1000, 4097]))
+        theta = float(rng.choice([1.0, 0.5, 0.3, 1.5]))
+        b = mod.make(kind, n, rng)
+        ot = O.Tree(b.n).build(b, 400.0)
+        if ot.nodes_used >= 32 * b.n - 8:
+            continue                                   # the reference exhausts its pool on this input
+        ax, ay, _, tree, cnt = gpu_bh(nb, b, theta=theta, want_tree=True)
+        ox, oy, ocnt = ot.accel(b, theta)
+        assert len(tree) == ot.nodes_used, (r, kind, b.n)
+        assert cnt == ocnt, (r, kind, b.n)
+        assert np.array_equal(ax, ox.astype(np.float32)) and np.array_equal(ay, oy.astype(np.float32)), (r, kind, b.n)
+        checked += 1
+    assert checked >= 35

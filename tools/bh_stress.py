@@ -1,0 +1,80 @@
+"""Developer tool (test infrastructure: uses the oracle): randomized Barnes-Hut parity stress on the GPU — tree,
+counters and accelerations must equal the oracle's bits for adversarial inputs: lattices whose points lie ON split
+lines (second instances), tight clusters (deep trees), duplicates, bodies outside the box, random theta."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as e
+nb = e.load_package(); O = e.load_oracle()
+
+
+def make(kind, n, rng):
+    """Adversarial but LEGAL inputs: no two bodies share a position (the reference then recurses until its node pool
+    is exhausted, benchmark.cpp:102 — see tests/test_gpu_bh.py::test_coincident_bodies_terminate) and fewer bodies on
+    split lines than the tie buffer holds."""
+    b = O.init_disc(n, seed=int(rng.integers(1, 1 << 30)))
+    if kind == "lattice":                      # distinct multiples of 400/2^k: every point is on some split line
+        k = int(np.ceil(np.log2(max(4, n)) / 2)) + int(rng.integers(1, 3))
+        side = (1 << (k + 1)) + 1
+        cells = rng.choice(side * side, size=n, replace=False)
+        step = 400.0 / (1 << k)
+        b.posX = ((cells % side - (1 << k)) * step).astype(np.float32)
+        b.posY = ((cells // side - (1 << k)) * step).astype(np.float32)
+        off = rng.random(n) < 0.5               # half of them leave the lattice in x (still on a y line)
+        b.posX = np.where(off, b.posX + rng.uniform(0.01, 0.4, n).astype(np.float32) * np.float32(step), b.posX).astype(np.float32)
+    elif kind == "cluster":
+        c = rng.normal(0, 100, (4, 2))
+        which = rng.integers(0, 4, n)
+        s = 10.0 ** rng.uniform(-0.5, 1, 4)      # not tighter: bodies one ulp apart in x AND y send the reference's
+                                                # recursion to the end of its pool (and the oracle's stack with it)
+        b.posX = (c[which, 0] + rng.normal(0, 1, n) * s[which]).astype(np.float32)
+        b.posY = (c[which, 1] + rng.normal(0, 1, n) * s[which]).astype(np.float32)
+    elif kind == "wide":
+        b.posX = (b.posX * 2.0).astype(np.float32); b.posY = (b.posY * 2.0).astype(np.float32)
+    elif kind == "axis":                       # a third of the bodies on the two root split lines
+        b.posX[::6] = 0.0; b.posY[3::6] = 0.0
+    # drop exact duplicates (keep the first): legal input only
+    _, first = np.unique(np.stack([b.posX, b.posY], 1), axis=0, return_index=True)
+    if len(first) != n:
+        keep = np.sort(first)
+        c = O.Bodies(len(keep))
+        for f in c.FIELDS: setattr(c, f, getattr(b, f)[keep].copy())
+        b = c
+    return b
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    rng = np.random.default_rng(seed)
+    bad = 0
+    t0 = time.time()
+    for r in range(rounds):
+        kind = ["lattice", "cluster", "wide", "axis", "disc"][r % 5]
+        n = int(rng.choice([1, 2, 7, 8, 9, 63, 100, 1000, 4097, 20000]))
+        if kind in ("lattice", "axis", "cluster"): n = min(n, 4097)   # stay inside the tie buffer (4096 second instances)
+        theta = float(rng.choice([1.0, 0.5, 0.3, 1.5]))
+        b = make(kind, n, rng)
+        n = b.n
+        status = "ok"
+        try:
+            with nb.NBodySim(n, theta=theta, useBarnesHut=True) as sim:
+                sim.upload(*b.arrays()); sim.compute_accel().sync()
+                ax, ay = sim.accel(); cnt = sim.bh_counters(); nodes = sim.bh_tree(max_nodes=1); total = sim.bh_nodes_total
+            ot = O.Tree(n).build(b, 400.0)
+            ox, oy, ocnt = ot.accel(b, theta)
+            if ot.nodes_used >= 32 * n - 8: status = "skipped: the reference exhausts its node pool on this input"; bad -= 1
+            elif total != ot.nodes_used: status = f"NODES {total} != {ot.nodes_used}"
+            elif cnt != ocnt: status = f"COUNTERS {cnt} != {ocnt}"
+            elif not (np.array_equal(ax, ox.astype(np.float32)) and np.array_equal(ay, oy.astype(np.float32))): status = "ACCEL bits differ"
+        except nb.NBodyError as ex:
+            status = f"library error: {ex}"
+        if status != "ok": bad += 1
+        print(f"[{r:3d}] {kind:8s} n={n:6d} theta={theta:3.1f}: {status}", flush=True)
+    print(f"{rounds - bad}/{rounds} ok in {time.time() - t0:.1f}s", flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
