@@ -348,3 +348,30 @@ def test_sharded_driver_torch_plumbing(nb, O):
     assert np.array_equal(px, ref["posX"])
     for k in ref:
         assert np.array_equal(st[k], ref[k]), k
+
+
+def test_randomized_adversarial_inputs_vs_f64(nb, O):
+    """tools/naive_stress.py as a regression test: crowded, coincident, far-flung, per-body mass/radius (zero masses,
+    radii below 4 -> exact variant, other powers of two -> scaled variant) inputs at ragged N.  Gate: the error of the
+    fp32 accumulation relative to the SUM OF THE MAGNITUDES summed, <= 2e-6 (measured worst 1.3e-6); where terms cancel,
+    |a| itself is arbitrarily small and a gate relative to |a| says nothing about the kernel."""
+    import importlib.util, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "naive_stress.py")
+    spec = importlib.util.spec_from_file_location("naive_stress", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(7)
+    kinds = ["disc", "crowd", "coincident", "wide", "masses", "radii", "small_radii", "pow2"]
+    variants = set()
+    for r in range(24):
+        n = int(rng.choice([1, 7, 8, 9, 65, 255, 1000, 2049, 4097]))
+        rc = int(rng.integers(0, 2))
+        b = mod.make(kinds[r % len(kinds)], n, rng)
+        ax, ay, _, info = run_gpu(nb, b, ref_compat=rc)
+        variants.add(info["force_variant"])
+        rx, ry = O.naive_accel_f64(b, ref_compat=rc)
+        lim = n - n % 8 if rc else n
+        err = np.hypot(ax - rx, ay - ry)[:lim] / np.maximum(mod.sum_abs_terms(b)[:lim], 1e-300)
+        assert lim == 0 or err.max() <= 2e-6, (r, kinds[r % len(kinds)], n, err.max())
+        assert np.all(ax[lim:] == 0) and np.all(np.isfinite(ax)) and np.all(np.isfinite(ay))
+    assert variants == {1, 2, 3, 4} or variants >= {1, 3, 4}
