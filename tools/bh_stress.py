@@ -68,6 +68,18 @@ def main():
             elif total != ot.nodes_used: status = f"NODES {total} != {ot.nodes_used}"
             elif cnt != ocnt: status = f"COUNTERS {cnt} != {ocnt}"
             elif not (np.array_equal(ax, ox.astype(np.float32)) and np.array_equal(ay, oy.astype(np.float32))): status = "ACCEL bits differ"
+            else:                                   # and three fused walk+Euler steps against the oracle's stepping
+                rc = int(rng.integers(0, 2))
+                with nb.NBodySim(n, theta=theta, useBarnesHut=True, ref_compat=rc) as sim:
+                    sim.upload(*b.arrays()); sim.step(3).sync(); st = sim.download()
+                c = b.copy()
+                try:
+                    O.bh_steps(c, 400.0, theta, 0.05, 3, ref_compat=rc)
+                except TypeError:
+                    if rc: O.bh_steps(c, 400.0, theta, 0.05, 3)
+                    else: c = None
+                if c is not None and not all(np.array_equal(st[f], getattr(c, f)) for f in ("posX", "posY", "velX", "velY")):
+                    status = f"STATE after 3 steps differs (ref_compat={rc})"
         except nb.NBodyError as ex:
             status = f"library error: {ex}"
         if status != "ok": bad += 1
