@@ -503,9 +503,28 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* __re
                 body = vals[sq];
             }
         } else if (cntq >= 1) {
-            body = vals[s[q]];                                  // leaf (at the depth cap: first body only)
+            body = vals[s[q]];                                  // leaf
         }
         if (body >= 0) { cx = px[body]; cy = py[body]; cm = m[body]; }   // benchmark.cpp:89-92
+        if (child_base < 0 && cntq >= 2) {
+            // Several bodies in one cell that is not split further: closer together than the finest cell (the path
+            // key has 31 levels: 800/2^31 = 3.7e-7 at spread 400) or the pool is exhausted.  The reference keeps
+            // splitting such a cell (to its depth ~40-150, for coincident bodies until ITS pool is exhausted,
+            // benchmark.cpp:102); the subtree it gets has this total mass at this centre of mass, and bodies that
+            // close are indistinguishable for every other target, so the leaf stands for all of them (the self mask
+            // covers the first one only).
+            float ms = 0.0f, sx = 0.0f, sy = 0.0f;
+            for (int j = s[q]; j < s[q + 1]; ++j) {
+                const int bj = vals[j];
+                if (j > s[q] && bj == vals[j - 1]) continue;    // two instances of one body
+                const float mj = m[bj];
+                ms += mj;
+                sx = __builtin_fmaf(px[bj], mj, sx);
+                sy = __builtin_fmaf(py[bj], mj, sy);
+            }
+            cm = ms;
+            if (ms > 0.0f) { cx = sx / ms; cy = sy / ms; }
+        }
         t.A[node] = make_float4(cx, cy, cm, width);
         t.B[node] = make_int2(child_base, body);
     }

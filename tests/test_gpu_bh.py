@@ -371,3 +371,23 @@ def test_randomized_adversarial_inputs_equal_the_oracle(nb, O):
         assert np.array_equal(ax, ox.astype(np.float32)) and np.array_equal(ay, oy.astype(np.float32)), (r, kind, b.n)
         checked += 1
     assert checked >= 35
+
+
+def test_bodies_closer_than_the_finest_cell_keep_their_mass(nb, O):
+    """Two DISTINCT bodies 2e-8 apart cannot be separated by a 31-level path key (finest cell 3.7e-7).  The reference
+    just keeps splitting (here to depth ~36); the GPU tree ends in one leaf carrying both masses at their centre of
+    mass.  Everybody else must feel the same force as from the reference's deeper subtree."""
+    n = 2048
+    b = O.init_disc(n, seed=17)
+    b.posX[5], b.posY[5] = np.float32(0.0123), np.float32(-0.0456)
+    b.posX[900], b.posY[900] = np.float32(0.0123) + np.float32(2e-8), np.float32(-0.0456)
+    assert b.posX[900] != b.posX[5]
+    ax, ay, _, tree, cnt = gpu_bh(nb, b, want_tree=True)
+    ot = O.Tree(n).build(b, 400.0)
+    assert ot.nodes_used < 32 * n - 8 and ot.nodes_used > len(tree)        # the reference went deeper, pool intact
+    assert tree[0]["mass"] == ot.pool()[0]["mass"]                          # nobody is lost from the tree
+    ox, oy, _ = ot.accel(b, 1.0)
+    others = np.ones(n, bool); others[[5, 900]] = False
+    others[n - n % 8:] = False
+    e = rel_err(ax[others], ay[others], ox[others], oy[others])
+    assert e.max() <= 1e-5, e.max()
