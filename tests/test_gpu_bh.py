@@ -161,11 +161,15 @@ def test_ref_compat_off_advances_tail_bodies(nb, O):
     assert np.array_equal(ax[:1000], ax1[:1000])
 
 
-def test_two_shards_equal_one(nb, O):
-    n = 4096
+@pytest.mark.parametrize("n,world", [(4096, 2), (5003, 3), (10000, 8), (37, 8)])
+def test_shards_equal_one(nb, O, n, world):
+    """One context per shard (what each rank of a multi-GPU run holds): every shard builds the same tree and walks its
+    own groups, so the pieces put together are the unsharded step bit for bit — also for ragged N and more ranks than
+    groups (empty shards)."""
     b = O.init_disc(n, seed=2)
     ax, ay, ref, _, _ = gpu_bh(nb, b, nsteps=1)
-    spans = [nb.shard_range(n, 2, r) for r in range(2)]
+    spans = [nb.shard_range(n, world, r) for r in range(world)]
+    assert sum(c for _, c in spans) == n
     got = {k: np.zeros(n, np.float32) for k in ("posX", "posY", "velX", "velY")}
     for beg, cnt in spans:
         with nb.NBodySim(n, dt=0.05, useBarnesHut=True, shard=(beg, cnt)) as sim:
