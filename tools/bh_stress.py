@@ -48,6 +48,8 @@ def main():
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 60
     rng = np.random.default_rng(seed)
+    fast = "--fast" in sys.argv          # bh_fast_math: same node count and counters required, accelerations to 1e-4
+    adaptive = "--adaptive" in sys.argv  # adaptive_box: the oracle gets the bounding half-width as its `spread`
     bad = 0
     t0 = time.time()
     for r in range(rounds):
@@ -59,17 +61,23 @@ def main():
         n = b.n
         status = "ok"
         try:
-            with nb.NBodySim(n, theta=theta, useBarnesHut=True) as sim:
+            box = float(max(np.abs(b.posX).max(), np.abs(b.posY).max())) if adaptive else 400.0
+            if box == 0.0: box = 1e-30
+            with nb.NBodySim(n, theta=theta, useBarnesHut=True, bh_fast_math=fast, adaptive_box=adaptive) as sim:
                 sim.upload(*b.arrays()); sim.compute_accel().sync()
                 ax, ay = sim.accel(); cnt = sim.bh_counters(); nodes = sim.bh_tree(max_nodes=1); total = sim.bh_nodes_total
-            ot = O.Tree(n).build(b, 400.0)
+            ot = O.Tree(n).build(b, box)
             ox, oy, ocnt = ot.accel(b, theta)
             if ot.nodes_used >= 32 * n - 8: status = "skipped: the reference exhausts its node pool on this input"; bad -= 1
             elif total != ot.nodes_used: status = f"NODES {total} != {ot.nodes_used}"
             elif cnt != ocnt: status = f"COUNTERS {cnt} != {ocnt}"
+            elif fast:
+                err = np.hypot(ax - ox, ay - oy) / np.maximum(np.hypot(ox, oy), 1e-30)
+                if np.nanmax(err) > 1e-4: status = f"ACCEL (fast math) off by {np.nanmax(err):.2e}"
             elif not (np.array_equal(ax, ox.astype(np.float32)) and np.array_equal(ay, oy.astype(np.float32))): status = "ACCEL bits differ"
             else:                                   # and three fused walk+Euler steps against the oracle's stepping
                 rc = int(rng.integers(0, 2))
+                if adaptive: raise StopIteration
                 with nb.NBodySim(n, theta=theta, useBarnesHut=True, ref_compat=rc) as sim:
                     sim.upload(*b.arrays()); sim.step(3).sync(); st = sim.download()
                 c = b.copy()
@@ -80,6 +88,8 @@ def main():
                     else: c = None
                 if c is not None and not all(np.array_equal(st[f], getattr(c, f)) for f in ("posX", "posY", "velX", "velY")):
                     status = f"STATE after 3 steps differs (ref_compat={rc})"
+        except StopIteration:
+            pass
         except nb.NBodyError as ex:
             status = f"library error: {ex}"
         if status != "ok": bad += 1
