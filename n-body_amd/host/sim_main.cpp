@@ -10,7 +10,7 @@
 // nbody_frame_acquire) and are "rendered" while step f+1 already runs on the GPU; "Physics" then reports the
 // time the host waited for the GPU in that frame.
 //
-//   nbody_sim [--frames K] [--seed s] [--config path] [--dump-pgm DIR] [--async-frames] [--no-log]
+//   nbody_sim [--frames K] [--seed s] [--config path] [--dump-pgm DIR] [--async-frames] [--no-log] [--print-config]
 #include "nbody.h"
 #include "config_reader.hpp"
 #include "initial_conditions.hpp"
@@ -45,7 +45,7 @@ int main(int argc, char** argv)
     int frames = 100;
     uint32_t seed = 12345u;
     std::string config_name = "config.json", dump_dir;
-    bool write_log = true, async_frames = false;
+    bool write_log = true, async_frames = false, print_config = false;
     for (int i = 1; i < argc; ++i) {
         auto next = [&](const char* flag) -> const char* {
             if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", flag); std::exit(2); }
@@ -57,10 +57,17 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--dump-pgm")) dump_dir = next("--dump-pgm");
         else if (!std::strcmp(argv[i], "--no-log")) write_log = false;
         else if (!std::strcmp(argv[i], "--async-frames")) async_frames = true;
+        else if (!std::strcmp(argv[i], "--print-config")) print_config = true;
         else { std::fprintf(stderr, "unknown flag %s\n", argv[i]); return 2; }
     }
 
     const nbody_host::SimConfig sc = nbody_host::load_config(config_name);
+    if (print_config) {          // what the reader made of the file (no GPU needed); one field per line
+        std::printf("useBarnesHut=%d\nuseParallel=%d\nnumBodies=%d\nspread=%.9g\nmass=%.9g\ntheta=%.9g\ndt=%.9g\nwindowSize=%d\nwindowTitle=%s\n",
+                    (int)sc.useBarnesHut, (int)sc.useParallel, sc.numBodies, sc.spread, sc.mass, sc.theta, sc.dt, sc.windowSize,
+                    sc.windowTitle.c_str());
+        return 0;
+    }
     nbody_config cfg;
     nbody_default_config(&cfg);
     cfg.num_bodies = sc.numBodies;

@@ -276,3 +276,38 @@ def ref_run(n, *, use_barnes_hut, nsteps, bodies=None, seed=12345, spread=400.0,
         pool = pool[:used.value].copy()
     return dict(init=init, final=final, acc=(ax, ay), nodes_used=used.value, root=root, pool=pool,
                 step_ms=ms[:nsteps])
+
+
+# ---------------------------------------------------------------------------------------------
+# main.cpp's own config.json reader (oracle/_ref/libnbody_ref_config.so)
+# ---------------------------------------------------------------------------------------------
+REF_CONFIG_SO = os.path.join(_HERE, "_ref", "libnbody_ref_config.so")
+
+
+class _RefConfig(C.Structure):
+    _fields_ = [("useBarnesHut", C.c_int), ("useParallel", C.c_int), ("numBodies", C.c_int), ("spread", C.c_float),
+                ("mass", C.c_float), ("theta", C.c_float), ("dt", C.c_float), ("windowSize", C.c_int),
+                ("windowTitle", C.c_char * 256), ("threw", C.c_int)]
+
+
+_ref_config = None
+
+
+def ref_config_available():
+    return os.path.exists(REF_CONFIG_SO)
+
+
+def ref_parse_config(filename="config.json"):
+    """The reference's findConfigFile + parameter block (main.cpp:26-56, 337-402) on `filename`, searched from the
+    CURRENT working directory as the reference does.  Returns a dict, or None when its stoi/stod threw."""
+    global _ref_config
+    if _ref_config is None:
+        _ref_config = C.CDLL(REF_CONFIG_SO)
+        _ref_config.ref_main_parse_config.argtypes = [C.c_char_p, C.POINTER(_RefConfig)]
+    out = _RefConfig()
+    _ref_config.ref_main_parse_config(filename.encode(), C.byref(out))
+    if out.threw:
+        return None
+    return dict(useBarnesHut=out.useBarnesHut, useParallel=out.useParallel, numBodies=out.numBodies, spread=out.spread,
+                mass=out.mass, theta=out.theta, dt=out.dt, windowSize=out.windowSize,
+                windowTitle=out.windowTitle.decode(errors="replace"))

@@ -98,3 +98,24 @@ rm -f "$OUT_DIR/nbody_ref_dropin.o"
 echo "build_ref: built $OUT_DIR/libnbody_ref_dropin.so (reference harness + GPU physics)"
 fi
 
+# ---- config reader: main.cpp's own findConfigFile (26-56) and parameter block (337-402), nothing else of that file ----
+MAIN_SRC="$(dirname "$REF_SRC")/main.cpp"
+MAIN_PIN="e44086afbcd232ec9e00df38a96be942083f7510f039cdf9d363923d04807610"
+if [ -f "$MAIN_SRC" ]; then
+    GOT="$(sha256sum "$MAIN_SRC" | cut -d' ' -f1)"
+    if [ "$GOT" != "$MAIN_PIN" ]; then echo "build_ref: main.cpp sha256 $GOT != pinned $MAIN_PIN" >&2; exit 1; fi
+    awk '
+    function expect(re) { if ($0 !~ re) { printf("build_ref(config): line %d does not match /%s/: %s\n", NR, re, $0) > "/dev/stderr"; bad = 1 } }
+    NR==26  { expect("namespace fs = std::filesystem"); }
+    NR==29  { expect("std::string findConfigFile"); }
+    NR>=26 && NR<=56 { print; next }
+    NR==334 { expect("^int main\\(\\)"); print "extern \"C\" int ref_main_parse_config(const char *filename, RefConfig *out)"; print "{ out->threw = 0; try {"; next }
+    NR==337 { expect("bool useBarnesHut = true"); }
+    NR==348 { expect("findConfigFile\\(\"config.json\"\\)"); print "    std::string configPath = findConfigFile(filename);"; next }
+    NR==402 { expect("^    }"); print; print "    REF_CONFIG_OUT();"; print "    return 0; } catch (...) { out->threw = 1; return 1; } }"; next }
+    NR>=336 && NR<402 { print; next }
+    END { if (bad) exit 3 }
+    ' "$MAIN_SRC" | g++ -std=c++17 -O2 -fPIC -shared -include "$HERE/config_hooks.h" -x c++ - -o "$OUT_DIR/libnbody_ref_config.so"
+    echo "build_ref: built $OUT_DIR/libnbody_ref_config.so (main.cpp config reader)"
+fi
+

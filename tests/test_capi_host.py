@@ -224,3 +224,62 @@ def test_cpp_driver_bootstrap_hands_the_comm_id_to_every_rank(tmp_path):
     for k in range(128):
         want = (want * 31 + ((k * 7 + 3) & 0xFF)) & 0xFFFFFFFF
     assert sums == {str(want)}
+
+
+def test_config_reader_equals_the_references_own_code_on_random_files(O, tmp_path):
+    """host/config_reader.hpp against main.cpp's own findConfigFile + parameter block (compiled from /root/reference by
+    oracle/build_ref.sh into oracle/_ref/libnbody_ref_config.so) on generated files: nested or flat objects, keys in
+    any order or missing, blanks before commas/braces (which turn `true }` into false), quoted numbers, duplicate
+    keys, keys hidden inside the title string, garbage numbers (the reference's stoi/stod then throws: both fail)."""
+    if not O.ref_config_available():
+        pytest.skip("oracle/_ref/libnbody_ref_config.so was not built (needs /root/reference at build time)")
+    rng = np.random.default_rng(99)
+    exe = os.path.join(ROOT, "n-body_amd", "bin", "nbody_sim")
+
+    def token(kind):
+        r = rng.random()
+        if kind == "bool":
+            return rng.choice(["true", "false", "true ", " false", "True", "1", '"true"'])
+        if kind == "int":
+            v = str(int(rng.integers(1, 200000)))
+            return rng.choice([v, v + " ", '"' + v + '"', v + ".7", "  " + v, "x" + v]) if r < 0.9 else "none"
+        v = "%g" % rng.uniform(0.001, 5000)
+        return rng.choice([v, v + "  ", '"' + v + '"', v + "e1", "-" + v, v + "f"]) if r < 0.92 else "abc"
+
+    keys = [("useBarnesHut", "bool"), ("useParallel", "bool"), ("numBodies", "int"), ("spread", "float"), ("mass", "float"),
+            ("theta", "float"), ("dt", "float"), ("windowSize", "int")]
+    cwd = os.getcwd()
+    agreed = failed_both = 0
+    try:
+        for trial in range(120):
+            d = tmp_path / f"t{trial}"
+            d.mkdir()
+            items = [(k, token(t)) for k, t in keys if rng.random() < 0.85]
+            if rng.random() < 0.6:
+                items.append(("windowTitle", rng.choice(['"plain"', '"has \\"numBodies\\": 5 inside"', '"a, b } c"', '""'])))
+            if rng.random() < 0.3 and items:
+                items.append(items[int(rng.integers(0, len(items)))])            # duplicate key: the first one wins
+            order = rng.permutation(len(items))
+            sep = rng.choice([", ", ",\n  ", " ,", ","])
+            body = sep.join('"%s"%s:%s%s' % (items[i][0], rng.choice(["", " "]), rng.choice(["", " ", "\n"]), items[i][1]) for i in order)
+            text = "{ %s%s }" % (rng.choice(["", '"simulation": { ']), body) + rng.choice(["", " }", "\n"])
+            (d / "config.json").write_text(text)
+            os.chdir(d)
+            want = O.ref_parse_config("config.json")
+            os.chdir(cwd)
+            r = subprocess.run([exe, "--print-config"], cwd=str(d), capture_output=True, text=True)
+            if want is None:
+                assert r.returncode != 0, (text, r.stdout)                          # both choke on the same file
+                failed_both += 1
+                continue
+            assert r.returncode == 0, (text, r.stderr)
+            got = dict(ln.split("=", 1) for ln in r.stdout.splitlines() if "=" in ln and not ln.startswith(("Config", "Search", "Found")))
+            for k in ("useBarnesHut", "useParallel", "numBodies", "windowSize"):
+                assert int(got[k]) == want[k], (k, text, got, want)
+            for k in ("spread", "mass", "theta", "dt"):
+                assert np.float32(float(got[k])) == np.float32(want[k]), (k, text, got, want)
+            assert got["windowTitle"] == want["windowTitle"], (text, got, want)
+            agreed += 1
+    finally:
+        os.chdir(cwd)
+    assert agreed >= 60 and failed_both >= 3
