@@ -49,7 +49,9 @@ typedef struct nbody_config {
                                 nor integrated (benchmark.cpp:423,486,368) and the BH walk votes per group of 8
                                 consecutive bodies (benchmark.cpp:264-266).
                                 2: main.cpp's flavour of the same — identical, except that its Barnes-Hut branch lets
-                                the N%8 tail bodies drift force-free, pos += vel*dt (main.cpp:535-544).
+                                the N%8 tail bodies drift force-free, pos += vel*dt (main.cpp:535-544), and that its
+                                tree normalises a centre of mass as sum * (1/mass) (main.cpp:173-175) where
+                                benchmark.cpp divides twice (benchmark.cpp:139-140): a last-bit difference.
                                 0: every body is a target; BH walk still uses the group-of-8 vote.                 */
     int32_t device;          /* HIP device ordinal; -1 = current device                           */
     /* i-body shard owned by this context (multi-GPU: one context per GPU/process).

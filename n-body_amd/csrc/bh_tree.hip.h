@@ -68,6 +68,7 @@ struct BhTree {
     uint8_t* __restrict__ depth;         // per internal cell
     int* __restrict__ self;              // per internal cell: its node index
     int cap_internal;
+    int com_reciprocal;                  // 1: com = sum * (1/mass) as main.cpp:173-175 does; 0: sum / mass (benchmark.cpp:139-140)
 };
 
 __device__ __forceinline__ int bh_lcp_levels(uint64_t a, uint64_t b)
@@ -571,7 +572,11 @@ __device__ __forceinline__ void bh_com_cell(const BhTree& t, int c)
     // {comX, comY, mass} are written: the width in .w stays, so the record is not read first (one round trip less
     // per level of the bottom-up chain).
     float* rec = reinterpret_cast<float*>(t.A + self);
-    const float cx = ms > 0.0f ? sx / ms : 0.0f, cy = ms > 0.0f ? sy / ms : 0.0f;
+    float cx = 0.0f, cy = 0.0f;
+    if (ms > 0.0f) {
+        if (t.com_reciprocal) { const float inv = 1.0f / ms; cx = sx * inv; cy = sy * inv; }
+        else                  { cx = sx / ms; cy = sy / ms; }
+    }
     rec[0] = cx; rec[1] = cy; rec[2] = ms;
 }
 

@@ -425,6 +425,7 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
         // the reference reserves 32 N nodes (benchmark.cpp:148) and uses ~2.9 N;
         // here: 2 N + 64 internal cells => 8 N + 257 nodes of 24 B
         b.tree.cap_internal = 2 * n + 64;
+        b.tree.com_reciprocal = cfg->ref_compat == 2;   // main.cpp's tree arithmetic (main.cpp:173-175)
         b.node_cap = 1 + 4 * (int64_t)b.tree.cap_internal;
         HIP_TRY_C(hipMalloc((void**)&b.keys, sizeof(uint64_t) * (size_t)n));
         HIP_TRY_C(hipMalloc((void**)&b.keys_sorted, sizeof(uint64_t) * (size_t)n));

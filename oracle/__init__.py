@@ -14,6 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(_HERE, "libnbody_oracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libnbody_ref.so")
+REF_MAINPHYS_SO = os.path.join(_HERE, "_ref", "libnbody_ref_mainphys.so")       # main.cpp's physics block (485-642)
 REF_DROPIN_SO = os.path.join(_HERE, "_ref", "libnbody_ref_dropin.so")   # same file, physics block -> include/nbody.h
 
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
@@ -179,6 +180,12 @@ class Tree:
             pass
 
 
+def set_main_cpp_flavour(on):
+    """Tree arithmetic of main.cpp (centre of mass = sum * (1/mass), main.cpp:173-175) instead of benchmark.cpp's
+    (sum / mass) for every tree built from now on."""
+    lib().oracle_set_main_cpp_flavour(int(bool(on)))
+
+
 def bh_steps(b, spread, theta, dt, nsteps, use_parallel=1):
     lib().oracle_bh_steps(b.n, *b.arrays(), spread, theta, dt, nsteps, use_parallel)
     return b
@@ -212,20 +219,37 @@ def ref_dropin_available():
     return os.path.exists(REF_DROPIN_SO)
 
 
+def ref_mainphys_available():
+    return os.path.exists(REF_MAINPHYS_SO)
+
+
+_ref_mainphys = None
+
+
 def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
 def ref_run(n, *, use_barnes_hut, nsteps, bodies=None, seed=12345, spread=400.0, mass=1000.0, theta=1.0,
-            dt=0.05, use_parallel=1, want_pool=False, dropin=False):
+            dt=0.05, use_parallel=1, want_pool=False, dropin=False, main_cpp=False):
     """Run the compiled reference loop (benchmark.cpp:349-557) for nsteps.
 
     bodies=None -> the reference's own generator (benchmark.cpp:317-339) with `seed`.
+    main_cpp=True -> main.cpp's physics block (main.cpp:485-642; needs `bodies`, no tree/acceleration read-back) instead
+    of benchmark.cpp's.
     dropin=True -> the DROP-IN build: the same reference program with its physics block replaced by the C-ABI
     (needs a GPU; tree read-back fields stay empty).
     Returns dict(init=Bodies, final=Bodies, acc=(ax, ay) of the last step, nodes_used, root, pool, step_ms)."""
-    global _ref, _ref_dropin
-    if dropin:
+    global _ref, _ref_dropin, _ref_mainphys
+    if main_cpp:
+        if bodies is None:
+            raise ValueError("main_cpp=True needs bodies (main.cpp's generator sits behind its SFML code)")
+        if _ref_mainphys is None:
+            _ref_mainphys = C.CDLL(REF_MAINPHYS_SO)
+            _ref_mainphys.ref_main_physics_run.argtypes = [C.POINTER(_RefIO)]
+            _ref_mainphys.ref_main_physics_run.restype = C.c_int
+        entry = _ref_mainphys.ref_main_physics_run
+    elif dropin:
         if _ref_dropin is None:
             _ref_dropin = C.CDLL(REF_DROPIN_SO)
             _ref_dropin.ref_benchmark_run_dropin.argtypes = [C.POINTER(_RefIO)]

@@ -119,3 +119,32 @@ if [ -f "$MAIN_SRC" ]; then
     echo "build_ref: built $OUT_DIR/libnbody_ref_config.so (main.cpp config reader)"
 fi
 
+# ---- main.cpp physics: its own SoA/QuadTree (2-315) and physics block (485-642) in a callable loop ----
+if [ -f "$MAIN_SRC" ]; then
+    awk '
+    function expect(re) { if ($0 !~ re) { printf("build_ref(mainphys): line %d does not match /%s/: %s\n", NR, re, $0) > "/dev/stderr"; bad = 1 } }
+    NR==1   { expect("SFML/Graphics.hpp"); next }
+    NR==107 { expect("private:"); print "public:"; next }
+    NR>=2 && NR<=315 { print; next }
+    NR==334 { expect("^int main\\(\\)");
+              print "extern \"C\" int ref_main_physics_run(RefIO *p)";
+              print "{";
+              print "    bool useBarnesHut = p->use_barnes_hut != 0, useParallel = p->use_parallel != 0;";
+              print "    int n = p->n; float spread = p->spread, theta = p->theta, dt = p->dt;";
+              print "    BodyDataSoA data; data.resize(n);";
+              print "    REF_AFTER_INIT(data);";
+              print "    QuadTree tree; tree.init(n, spread);";
+              print "    for (int ref_step = 0; ref_step < p->nsteps; ++ref_step) {";
+              next }
+    NR==485 { expect("if \\(useBarnesHut\\)"); }
+    NR==488 { expect("tree.build\\(data, spread\\)"); print; print "            REF_AFTER_BUILD(tree);"; next }
+    NR==642 { expect("^        }"); print; print "    }"; print "    REF_AFTER_LOOP(data);"; print "    return 0;"; print "}"; next }
+    NR>=485 && NR<642 { print; next }
+    END { if (bad) exit 3 }
+    ' "$MAIN_SRC" | g++ -std=c++17 -O3 -march=x86-64-v3 -ffast-math -mavx2 -mfma -fopenmp -DNDEBUG \
+        -fPIC -c -include "$HERE/mainphys_hooks.h" -x c++ - -o "$OUT_DIR/nbody_ref_mainphys.o"
+    g++ -shared -fopenmp "$OUT_DIR/nbody_ref_mainphys.o" -o "$OUT_DIR/libnbody_ref_mainphys.so" -lpthread
+    rm -f "$OUT_DIR/nbody_ref_mainphys.o"
+    echo "build_ref: built $OUT_DIR/libnbody_ref_mainphys.so (main.cpp physics block)"
+fi
+

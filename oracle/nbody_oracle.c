@@ -261,6 +261,13 @@ void oracle_diagnostics(int n, const float *m, const float *px, const float *py,
     out[0] = ek; out[1] = ep; out[2] = mx; out[3] = my; out[4] = lz;
 }
 
+/* The two reference programs differ in ONE arithmetic detail of the tree: main.cpp normalises a cell's centre of
+ * mass with a reciprocal and two products (main.cpp:173-175), benchmark.cpp with two divisions (benchmark.cpp:139-140).
+ * 0 = benchmark.cpp (default), 1 = main.cpp. */
+static int g_main_cpp_flavour = 0;
+void oracle_set_main_cpp_flavour(int on) { g_main_cpp_flavour = on != 0; }
+
+
 /* ------------------------------------------------------------------------------------ */
 /* A4: quadtree, benchmark.cpp:52-173.  48-byte nodes, fixed root box, capacity-1 leaves, */
 /* inclusive bounds on all four sides, children TL,TR,BL,BR, COM refreshed on unwind.     */
@@ -321,7 +328,14 @@ static void tree_insert(oracle_tree *t, int ni, int b, const float *m, const flo
         }
     }
     nd->mass = ms;
-    if (ms > 0.0f) { nd->comX = sx / ms; nd->comY = sy / ms; }                /* :137-141 */
+    if (ms > 0.0f) {
+        if (g_main_cpp_flavour) {                          /* main.cpp:173-175: one reciprocal, two products */
+            float inv = 1.0f / ms;
+            nd->comX = sx * inv; nd->comY = sy * inv;
+        } else {                                           /* benchmark.cpp:137-141: two divisions */
+            nd->comX = sx / ms; nd->comY = sy / ms;
+        }
+    }
 }
 
 oracle_tree *oracle_tree_create(int n)

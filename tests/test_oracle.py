@@ -195,3 +195,46 @@ def test_reference_live_if_present(O):
     r = O.ref_run(b.n, use_barnes_hut=0, nsteps=1, bodies=b, dt=float(g["dt"]))
     e = rel_err(r["acc"][0], r["acc"][1], g["accX"], g["accY"])
     assert np.percentile(e, 99) <= 3e-4
+
+
+@pytest.mark.parametrize("bh,n", [(0, 1000), (0, 1003), (1, 1000), (1, 1003), (1, 7)])
+def test_main_cpp_physics_vs_benchmark_cpp_physics(O, bh, n):
+    """main.cpp's physics block (main.cpp:485-642) against benchmark.cpp's, both compiled from
+    /root/reference (oracle/build_ref.sh) and run on the same bodies.  The naive branches are the same code: bit-identical.
+    The Barnes-Hut branches differ in two things, both mirrored by ref_compat = 2: main.cpp lets the N%8 tail bodies
+    drift force-free (main.cpp:535-544), and its tree normalises a centre of mass with one reciprocal and two products
+    where benchmark.cpp divides twice (main.cpp:173-175 vs benchmark.cpp:139-140) — a last-bit difference."""
+    if not (O.ref_available() and O.ref_mainphys_available()):
+        pytest.skip("oracle/_ref was not built (needs /root/reference at build time)")
+    b = O.init_disc(n, seed=33)
+    bench = O.ref_run(n, use_barnes_hut=bh, nsteps=1, bodies=b, want_pool=bool(bh))
+    main = O.ref_run(n, use_barnes_hut=bh, nsteps=1, bodies=b, main_cpp=True, want_pool=bool(bh))
+    lim = n - n % 8
+    for f in ("posX", "posY", "velX", "velY"):
+        x, y = getattr(bench["final"], f)[:lim], getattr(main["final"], f)[:lim]
+        if bh:
+            assert np.allclose(x, y, rtol=2e-5, atol=1e-5), f
+        else:
+            assert np.array_equal(x, y), f
+    for f in ("velX", "velY"):
+        assert np.array_equal(getattr(main["final"], f)[lim:], getattr(b, f)[lim:])      # never accelerated in either
+    for f, v in (("posX", "velX"), ("posY", "velY")):
+        assert np.array_equal(getattr(bench["final"], f)[lim:], getattr(b, f)[lim:])     # benchmark.cpp: frozen
+        if bh and n % 8:
+            drift = (getattr(b, f)[lim:].astype(np.float64) + getattr(b, v)[lim:].astype(np.float64) * np.float64(np.float32(0.05))).astype(np.float32)
+            assert np.allclose(getattr(main["final"], f)[lim:], drift, rtol=2e-7, atol=0)    # main.cpp: pos += vel*dt
+            assert not np.array_equal(getattr(main["final"], f)[lim:], getattr(b, f)[lim:])
+        else:
+            assert np.array_equal(getattr(main["final"], f)[lim:], getattr(b, f)[lim:])
+    if bh and n >= 1000:
+        # the oracle's tree in main.cpp flavour is main.cpp's own node pool, bit for bit (and not benchmark.cpp's)
+        try:
+            O.set_main_cpp_flavour(True)
+            t = O.Tree(n).build(b, 400.0)
+            pool = t.pool()
+        finally:
+            O.set_main_cpp_flavour(False)
+        assert t.nodes_used == main["nodes_used"] == bench["nodes_used"]
+        for f in ("tlX", "tlY", "brX", "brY", "bodyIndex", "children", "mass", "comX", "comY"):
+            assert np.array_equal(pool[f], main["pool"][f]), f
+        assert not (np.array_equal(main["pool"]["comX"], bench["pool"]["comX"]) and np.array_equal(main["pool"]["comY"], bench["pool"]["comY"]))
