@@ -356,3 +356,21 @@ def test_ref_compat_2_is_main_cpp_tail_bodies_drift_force_free(nb, O, n):
         for f in ("posX", "posY", "velX", "velY"):
             assert np.array_equal(one[f][:lim], getattr(c, f)[:lim]), f
         assert np.array_equal(canonical(tree), canonical(opool))
+
+
+def test_every_body_outside_the_root_box(nb, O):
+    """A root box that contains no body at all (the late state of the reference's unbound disc): the tree is one empty
+    node, nobody feels a force, everybody keeps drifting — as in the oracle."""
+    n = 1000
+    b = O.init_disc(n, seed=4)
+    b.posX += np.float32(50.0)                                   # the disc no longer touches [-1, 1]^2
+    keep = (np.abs(b.posX) > 1.0) | (np.abs(b.posY) > 1.0)
+    assert keep.all()
+    ax, ay, st, tree, cnt = gpu_bh(nb, b, spread=1.0, nsteps=2, want_tree=True)
+    assert len(tree) == 1 and tree[0]["mass"] == 0 and tree[0]["bodyIndex"] == -1
+    assert not ax.any() and not ay.any()
+    c = b.copy()
+    O.bh_steps(c, 1.0, 1.0, 0.05, 2)
+    for f in ("posX", "posY", "velX", "velY"):
+        assert np.array_equal(st[f], getattr(c, f)), f
+    assert cnt == dict(visits=n // 8, accepts=0)                 # every group looks at the empty root once
