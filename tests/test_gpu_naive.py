@@ -375,3 +375,28 @@ def test_randomized_adversarial_inputs_vs_f64(nb, O):
         assert lim == 0 or err.max() <= 2e-6, (r, kinds[r % len(kinds)], n, err.max())
         assert np.all(ax[lim:] == 0) and np.all(np.isfinite(ax)) and np.all(np.isfinite(ay))
     assert variants == {1, 2, 3, 4} or variants >= {1, 3, 4}
+
+
+@pytest.mark.parametrize("variant", [2, 3, 4])
+def test_other_variants_at_the_big_tile_geometry(nb, O, variant):
+    """Variants 2-4 (uniform / per-body / exact formula) are selected by data the reference never produces, so the
+    full-size tests above only ever run variant 1.  N = 2^18 puts them on the same launch geometry as the headline run
+    (K = 4 targets per lane, 2048-source tiles, several j-slices); 512 sampled targets against the f64 oracle."""
+    n = 1 << 18
+    b = O.init_disc(n, seed=77)
+    if variant == 3:
+        rng = np.random.default_rng(1)
+        b.m = (rng.random(n) * 2000.0 + 1.0).astype(np.float32)
+        b.radius = rng.uniform(4.0, 30.0, n).astype(np.float32)
+    elif variant == 4:
+        b.radius[:] = np.float32(0.5)
+    else:
+        b.radius[:] = np.float32(6.0)
+    ax, ay, _, info = run_gpu(nb, b, force_variant=variant)
+    assert info["force_variant"] == variant and info["j_slices"] >= 2
+    idx = np.linspace(0, n - 1, 512).astype(np.int32)
+    rx, ry = O.naive_accel_f64_subset(b, idx)
+    e = rel_err(ax[idx], ay[idx], rx, ry)
+    assert e.max() <= TOL_F64, e.max()
+    tot = np.abs(np.sum((b.m * ax).astype(np.float64))) + np.abs(np.sum((b.m * ay).astype(np.float64)))
+    assert tot <= 1e-5 * np.sum((b.m * np.hypot(ax, ay)).astype(np.float64))      # Newton's third law, mass-weighted
