@@ -52,3 +52,29 @@ def test_config5_plummer_16m_one_rank_of_eight(nb, O):
         hx, hy = sim.accel()
     sl = slice(half[0], half[0] + half[1])
     assert np.array_equal(hx[sl], ax[sl]) and np.array_equal(hy[sl], ay[sl])
+
+
+def test_plummer_4m_tree_and_sampled_walk_equal_the_oracle(nb, O):
+    """The clustered input at 2^22 bodies against the oracle itself (its serial insertion takes ~3 s and 6.4 GB here;
+    the 2^24 run of the same check is tools/bh_16m_exact.py, output in profiles/r1_bh_16m_plummer_vs_oracle.txt): node
+    count, root record, and accelerations + counters of the first 8192 targets, bit for bit — with ~1000 bodies on
+    split lines, some of them only through the tie fixed point."""
+    import ctypes as C
+    n, theta, nt = 1 << 22, 0.5, 8192
+    b = O.init_plummer(n, scale=50.0, seed=12345)
+    with nb.NBodySim(n, theta=theta, useBarnesHut=True, shard=(0, nt)) as sim:
+        sim.upload(*b.arrays())
+        sim.compute_accel().sync()
+        ax, ay = sim.accel()
+        root = sim.bh_tree(max_nodes=1)[0]
+        total = sim.bh_nodes_total
+        cnt = sim.bh_counters()
+    ot = O.Tree(n).build(b, 400.0)
+    assert total == ot.nodes_used
+    oroot = np.frombuffer((C.c_char * 48).from_address(O.lib().oracle_tree_pool(ot.h)), dtype=O.NODE_DTYPE)[0]
+    for f in ("mass", "comX", "comY"):
+        assert root[f] == oroot[f], f
+    ox = np.zeros(n); oy = np.zeros(n); oc = np.zeros(2, np.int64)
+    O.lib().oracle_bh_accel(ot.h, nt, b.posX, b.posY, b.radius, theta, 0, 8, ox, oy, oc)
+    assert cnt == dict(visits=int(oc[0]), accepts=int(oc[1]))
+    assert np.array_equal(ax[:nt], ox[:nt].astype(np.float32)) and np.array_equal(ay[:nt], oy[:nt].astype(np.float32))
