@@ -221,7 +221,8 @@ struct BhTies {
     int* __restrict__ glo;               // its neighbours among the sorted primaries (own primary skipped): indices,
     int* __restrict__ ghi;               //   -1 / M when there is none
     int* __restrict__ gpos;              // its insertion position among the sorted primaries
-    int* __restrict__ pld;               // leaf depth up to which the ties of body b's PRIMARY have been expanded
+    int* __restrict__ pld;               // per SORTED PRIMARY (index into keys): leaf depth up to which its ties have been
+                                         //   expanded; written for primaries with a recorded tie only
     int* __restrict__ table;             // open-addressing hash: insertion position -> instance index (-1 = empty);
     int table_mask;                      //   cleared by bh_keys_kernel, size = table_mask + 1 >= 2 * gcap
     int gcap;
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_ties_kernel(const uint64_t* __res
     const int lp = i > 0 ? bh_lcp_levels(keys[i - 1], k) : -1;
     const int ln = i + 1 < M ? bh_lcp_levels(k, keys[i + 1]) : -1;
     const int leaf_depth = 1 + (lp > ln ? lp : ln);              // 0 when the body is alone in the tree
-    T.pld[b] = leaf_depth;
+    T.pld[i] = leaf_depth;
     bh_spawn_ties(px[b], py[b], ctr->root_half, 0u, 0u, 0, leaf_depth, b, first, keys, vals, M, T, ctr);
 }
 
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(kBhFixBlock) void bh_tie_fixpoint_kernel(const uint
                 const int bj = vals[j];
                 const int first = bh_first_tie(tie[bj]);
                 if (first < d) {
-                    const int old = atomicMax(&T.pld[bj], d);
+                    const int old = atomicMax(&T.pld[j], d);
                     if (d > old) bh_spawn_ties(px[bj], py[bj], spread, 0u, 0u, old, d, bj, first, keys, vals, M, T, ctr);
                 }
             }
