@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -283,3 +284,18 @@ def test_config_reader_equals_the_references_own_code_on_random_files(O, tmp_pat
     finally:
         os.chdir(cwd)
     assert agreed >= 60 and failed_both >= 3
+
+
+def test_bench_fails_loudly_without_a_gpu():
+    """bench.py and smoke() are product-path callers: on a machine without an MI355X they must stop with a clear message,
+    not fall back to anything that runs on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--bodies", "1024"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())           # no JSON line without a measurement
+    import __graft_entry__ as entry
+    with pytest.raises(Exception, match="no HIP device|no CPU fallback"):
+        entry.smoke()
