@@ -158,6 +158,12 @@ int64_t nbody_bh_tree_nodes(nbody_ctx *ctx, void *out, int64_t cap);
 /* {node visits, accepted nodes} summed over all groups of the last BH walk. */
 int nbody_bh_counters(nbody_ctx *ctx, int64_t out[2]);
 
+/* The same two counters per group of 8 consecutive bodies (index = first body / 8; ceil(num_bodies/8) entries each;
+   groups outside the owned shard and the N%8 tail group keep 0): what the reference's vote (benchmark.cpp:259-266)
+   decides group by group.  Parity hook against the counters oracle/build_ref.sh exports from the compiled reference
+   at benchmark.cpp:245 (node popped) and :267 (node accepted).  Syncs. */
+int nbody_bh_group_counters(nbody_ctx *ctx, int32_t *visits, int32_t *accepts);
+
 const char *nbody_last_error(void); /* thread-local, never NULL */
 int nbody_abi_version(void);
 

@@ -25,6 +25,7 @@ ABI_SYMBOLS = (
     "nbody_frame_acquire", "nbody_comm_unique_id", "nbody_comm_init", "nbody_exchange_positions", "nbody_get_accel",
     "nbody_diagnostics", "nbody_device_ptr", "nbody_profile_enable", "nbody_profile_read",
     "nbody_profile_reset", "nbody_get_info", "nbody_bh_tree_nodes", "nbody_bh_counters",
+    "nbody_bh_group_counters",
     "nbody_last_error", "nbody_abi_version",
 )
 
@@ -83,6 +84,7 @@ def lib():
         L.nbody_bh_tree_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.nbody_bh_tree_nodes.restype = C.c_int64
         L.nbody_bh_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.nbody_bh_group_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.nbody_last_error.restype = C.c_char_p
         L.nbody_abi_version.restype = C.c_int
         _lib = L
@@ -244,7 +246,7 @@ class NBodySim:
     def bh_tree(self, max_nodes=None):
         """Node pool of the last build as 48-byte QuadNode records (benchmark.cpp:52-60); node 0 is the root.
         max_nodes limits the copy (a 2^24-body tree has ~4.6e7 nodes = 2.2 GB); len() of the result is then the
-        number copied, and .total the number of nodes in the tree."""
+        number copied, and self.bh_nodes_total the number of nodes in the tree."""
         n = lib().nbody_bh_tree_nodes(self._h, None, 0)
         if n < 0:
             raise NBodyError(int(n), lib().nbody_last_error().decode())
@@ -264,6 +266,14 @@ class NBodySim:
         out = (C.c_int64 * 2)()
         _check(lib().nbody_bh_counters(self._h, out))
         return dict(visits=out[0], accepts=out[1])
+
+    def bh_group_counters(self):
+        """(visits, accepts) of the last walk per group of 8 consecutive bodies (nbody_bh_group_counters)."""
+        g = (self.n + 7) // 8
+        v, a = np.zeros(g, np.int32), np.zeros(g, np.int32)
+        _check(lib().nbody_bh_group_counters(self._h, v.ctypes.data_as(C.POINTER(C.c_int32)),
+                                             a.ctypes.data_as(C.POINTER(C.c_int32))))
+        return v, a
 
     def close(self):
         if self._h:

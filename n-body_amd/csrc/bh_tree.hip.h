@@ -637,6 +637,8 @@ struct BhWalkArgs {
     int i_begin, i_end;              // targets; i_begin is a multiple of 8
     float theta;
     int lanes_used;                  // 8 x groups per wave (64, 32, 16 or 8): see bh_walk_groups_per_wave()
+    int* __restrict__ grp_visits;    // [n/8 + 1] per group of 8 bodies (index = first body / 8): nodes popped and
+    int* __restrict__ grp_accepts;   //           nodes accepted by this walk (parity hook, nbody_bh_group_counters)
 };
 
 // Groups per wave.  8 (all 64 lanes) is the throughput shape.  With few groups the walk is a latency chain and the
@@ -765,6 +767,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     }
 
     // counters: one representative lane per group
+    if ((tid & 7) == 0 && i < w.i_end && lane < w.lanes_used) { w.grp_visits[i >> 3] = (int)visits; w.grp_accepts[i >> 3] = (int)accepts; }
     unsigned long long v = (tid & 7) == 0 ? visits : 0, acc = (tid & 7) == 0 ? accepts : 0;
     for (int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); acc += __shfl_down(acc, off, 64); }
     if ((tid & 63) == 0) { red[0][tid >> 6] = v; red[1][tid >> 6] = acc; red[2][tid >> 6] = iters; }

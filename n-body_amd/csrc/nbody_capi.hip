@@ -110,6 +110,7 @@ struct nbody_ctx {
         size_t gsort_bytes = 0;
         BhTree tree{};
         BhCounters* ctr = nullptr;
+        int *grp_visits = nullptr, *grp_accepts = nullptr;   // per group of 8 bodies, written by every walk
         void *sort_tmp = nullptr, *scan_tmp = nullptr;
         size_t sort_bytes = 0, scan_bytes = 0;
         int64_t node_cap = 0;
@@ -283,6 +284,7 @@ int enqueue_bh_walk(nbody_ctx* ctx, int advance)
     w.px = ctx->px; w.py = ctx->py; w.radius = ctx->radius;
     w.vx = ctx->vx; w.vy = ctx->vy;
     w.ax = ctx->ax; w.ay = ctx->ay; w.ctr = ctx->bh.ctr;
+    w.grp_visits = ctx->bh.grp_visits; w.grp_accepts = ctx->bh.grp_accepts;
     w.dt = ctx->cfg.dt; w.advance = advance;
     w.i_begin = ctx->i_begin; w.i_end = ctx->i_end; w.theta = ctx->cfg.theta;
     const int nt = ctx->i_end - ctx->i_begin;
@@ -459,6 +461,10 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
         HIP_TRY_C(hipMalloc((void**)&b.tree.self, sizeof(int) * (size_t)b.tree.cap_internal));
         HIP_TRY_C(hipMalloc((void**)&b.ctr, sizeof(BhCounters)));
         HIP_TRY_C(hipMemset(b.ctr, 0, sizeof(BhCounters)));
+        HIP_TRY_C(hipMalloc((void**)&b.grp_visits, sizeof(int) * ((size_t)n / 8 + 1)));
+        HIP_TRY_C(hipMalloc((void**)&b.grp_accepts, sizeof(int) * ((size_t)n / 8 + 1)));
+        HIP_TRY_C(hipMemset(b.grp_visits, 0, sizeof(int) * ((size_t)n / 8 + 1)));
+        HIP_TRY_C(hipMemset(b.grp_accepts, 0, sizeof(int) * ((size_t)n / 8 + 1)));
         HIP_TRY_C(hipcub::DeviceRadixSort::SortPairs(nullptr, b.sort_bytes, b.keys, b.keys_sorted, b.vals, b.vals_sorted, n, 0, 64, ctx->stream));
         HIP_TRY_C(hipcub::DeviceRadixSort::SortPairs(nullptr, b.gsort_bytes, b.gkeys, b.gkeys_sorted, b.gvals, b.gvals_sorted, b.gcap, 0, 64, ctx->stream));
         HIP_TRY_C(hipcub::DeviceScan::ExclusiveSum(nullptr, b.scan_bytes, b.cnt, b.base, (int)nm, ctx->stream));
@@ -486,7 +492,7 @@ void nbody_destroy(nbody_ctx* ctx)
         auto& b = ctx->bh;
         void* ptrs[] = {b.keys, b.keys_sorted, b.vals, b.vals_sorted, b.cnt, b.base, b.tree.A, b.tree.B,
                         b.tree.depth, b.tree.self, b.ctr, b.tie, b.owner, b.gfx, b.gfy, b.gld, b.pld, b.glo, b.ghi, b.gpos, b.tie_table, b.sort_tmp, b.scan_tmp, b.gkeys, b.gkeys_sorted, b.gvals,
-                        b.gvals_sorted, b.keys_merged, b.vals_merged, b.gsort_tmp};
+                        b.gvals_sorted, b.keys_merged, b.vals_merged, b.gsort_tmp, b.grp_visits, b.grp_accepts};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
@@ -913,6 +919,18 @@ int nbody_bh_counters(nbody_ctx* ctx, int64_t out[2])
                              "%d second instances (bodies on split lines), %d valid instances, %d internal cells\n",
                      h.visits, h.wave_iters, h.wave_iters ? 100.0 * (double)h.visits / (8.0 * (double)h.wave_iters) : 0.0,
                      h.ghosts, h.valid, h.internal);
+    return NBODY_OK;
+}
+
+int nbody_bh_group_counters(nbody_ctx* ctx, int32_t* visits, int32_t* accepts)
+{
+    if (!ctx || !visits || !accepts) return fail(NBODY_ERR_INVALID, "nbody_bh_group_counters: null argument");
+    if (!ctx->cfg.use_barnes_hut) return fail(NBODY_ERR_INVALID, "nbody_bh_group_counters: context is not in Barnes-Hut mode");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const size_t nb = sizeof(int) * (size_t)((ctx->cfg.num_bodies + 7) / 8);
+    HIP_TRY(hipMemcpy(visits, ctx->bh.grp_visits, nb, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(accepts, ctx->bh.grp_accepts, nb, hipMemcpyDeviceToHost));
     return NBODY_OK;
 }
 

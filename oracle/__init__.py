@@ -54,7 +54,10 @@ def lib():
         L.oracle_tree_stats.argtypes = [C.c_void_p, _i32p]
         L.oracle_bh_accel.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, _f32p, C.c_float, C.c_int, C.c_int,
                                       _f64p, _f64p, _i64p]
+        L.oracle_bh_group_counters.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, _f32p, C.c_float, _i32p, _i32p,
+                                               np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]
         L.oracle_bh_steps.argtypes = [C.c_int] + [_f32p] * 6 + [C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
+        L.oracle_bh_steps_counted.argtypes = L.oracle_bh_steps.argtypes + [_i64p, _i64p]
         _lib = L
     return _lib
 
@@ -173,6 +176,13 @@ class Tree:
         lib().oracle_bh_accel(self.h, b.n, b.posX, b.posY, b.radius, theta, int(f64), group_size, ax, ay, cnt)
         return ax, ay, dict(visits=int(cnt[0]), accepts=int(cnt[1]))
 
+    def group_counters(self, b, theta):
+        """Per group of 8 bodies: (visits, accepts, hash of the accepted node indices in walk order)."""
+        g = b.n // 8
+        v = np.zeros(g, np.int32); a = np.zeros(g, np.int32); h = np.zeros(g, np.uint64)
+        lib().oracle_bh_group_counters(self.h, b.n, b.posX, b.posY, b.radius, theta, v, a, h)
+        return v, a, h
+
     def __del__(self):
         try:
             lib().oracle_tree_destroy(self.h)
@@ -191,6 +201,13 @@ def bh_steps(b, spread, theta, dt, nsteps, use_parallel=1):
     return b
 
 
+def bh_steps_counted(b, spread, theta, dt, nsteps):
+    """bh_steps + the walk's {visits, accepts} totals of every step."""
+    sv = np.zeros(max(nsteps, 1), np.int64); sa = np.zeros(max(nsteps, 1), np.int64)
+    lib().oracle_bh_steps_counted(b.n, *b.arrays(), spread, theta, dt, nsteps, 1, sv, sa)
+    return sv[:nsteps], sa[:nsteps]
+
+
 # ---------------------------------------------------------------------------------------------
 # The reference itself (oracle/_ref/libnbody_ref.so)
 # ---------------------------------------------------------------------------------------------
@@ -204,7 +221,10 @@ class _RefIO(C.Structure):
                 + [(k, C.POINTER(C.c_float)) for k in ("out_px", "out_py", "out_vx", "out_vy", "acc_x", "acc_y")]
                 + [("tree_nodes_used", C.POINTER(C.c_int)), ("tree_root", C.POINTER(C.c_float)),
                    ("tree_pool_out", C.c_void_p), ("tree_pool_cap", C.c_int),
-                   ("step_ms", C.POINTER(C.c_double))])
+                   ("step_ms", C.POINTER(C.c_double)),
+                   ("grp_visits", C.POINTER(C.c_int)), ("grp_accepts", C.POINTER(C.c_int)),
+                   ("grp_hash", C.POINTER(C.c_ulonglong)),
+                   ("step_visits", C.POINTER(C.c_longlong)), ("step_accepts", C.POINTER(C.c_longlong))])
 
 
 _ref = None
@@ -290,6 +310,15 @@ def ref_run(n, *, use_barnes_hut, nsteps, bodies=None, seed=12345, spread=400.0,
         io.tree_pool_cap = cap
     ms = np.zeros(max(nsteps, 1))
     io.step_ms = ms.ctypes.data_as(C.POINTER(C.c_double))
+    groups = max(n // 8, 1)
+    gv = np.zeros(groups, np.int32); ga = np.zeros(groups, np.int32); gh = np.zeros(groups, np.uint64)
+    sv = np.zeros(max(nsteps, 1), np.int64); sa = np.zeros(max(nsteps, 1), np.int64)
+    if use_barnes_hut and not main_cpp and not dropin:
+        io.grp_visits = gv.ctypes.data_as(C.POINTER(C.c_int))
+        io.grp_accepts = ga.ctypes.data_as(C.POINTER(C.c_int))
+        io.grp_hash = gh.ctypes.data_as(C.POINTER(C.c_ulonglong))
+        io.step_visits = sv.ctypes.data_as(C.POINTER(C.c_longlong))
+        io.step_accepts = sa.ctypes.data_as(C.POINTER(C.c_longlong))
     rc = entry(C.byref(io))
     if rc != 0:
         raise RuntimeError(f"ref_benchmark_run returned {rc}")
@@ -299,7 +328,11 @@ def ref_run(n, *, use_barnes_hut, nsteps, bodies=None, seed=12345, spread=400.0,
     if pool is not None:
         pool = pool[:used.value].copy()
     return dict(init=init, final=final, acc=(ax, ay), nodes_used=used.value, root=root, pool=pool,
-                step_ms=ms[:nsteps])
+                step_ms=ms[:nsteps],
+                # the reference's own vote (benchmark.cpp:242-276): per group of 8, accumulated over the nsteps of this
+                # run, and the totals of every step
+                grp_visits=gv[:n // 8], grp_accepts=ga[:n // 8], grp_hash=gh[:n // 8],
+                step_visits=sv[:nsteps], step_accepts=sa[:nsteps])
 
 
 # ---------------------------------------------------------------------------------------------

@@ -33,6 +33,8 @@ mkdir -p "$OUT_DIR"
 awk '
 function expect(re) { if ($0 !~ re) { printf("build_ref: line %d does not match /%s/: %s\n", NR, re, $0) > "/dev/stderr"; bad = 1 } }
 NR==72  { expect("private:");                 print "public:"; next }
+NR==245 { expect("node_stack.pop_back\\(\\)");  print; print "            REF_VISIT(start_index);"; next }
+NR==267 { expect("^            \\{");           print; print "                REF_ACCEPT(start_index, current_node_idx);"; next }
 NR==297 { expect("^int main\\(\\)");          print "extern \"C\" int ref_benchmark_run(RefIO *p)"; next }
 NR==300 { expect("bool useBarnesHut = true"); print "    bool useBarnesHut = p->use_barnes_hut != 0;"; next }
 NR==301 { expect("bool useParallel = true");  print "    bool useParallel = p->use_parallel != 0;"; next }

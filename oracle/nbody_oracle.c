@@ -389,7 +389,7 @@ void oracle_tree_stats(const oracle_tree *t, int out[4])
 /* ------------------------------------------------------------------------------------ */
 static void bh_group(const oracle_tree *t, int start, int lanes, const float *px, const float *py,
                      const float *radius, float theta, int use_f64, double *ax, double *ay,
-                     long long *visits, long long *accepts)
+                     long long *visits, long long *accepts, unsigned long long *accept_hash)
 {
     const float eps = 1e-6f, soft = 0.001f;
     double accx[VEC_STRIDE] = {0}, accy[VEC_STRIDE] = {0};
@@ -413,6 +413,7 @@ static void bh_group(const oracle_tree *t, int start, int lanes, const float *px
         int leaf = nd->children[0] == -1;
         if (leaf || all_far) {                                                /* :266 */
             if (accepts) ++*accepts;
+            if (accept_hash) *accept_hash = (*accept_hash ^ (unsigned long long)(unsigned)ni) * 1099511628211ull;
             for (int k = 0; k < lanes; ++k) {                                 /* A6, :176-225 */
                 if ((float)nd->bodyIndex == (float)(start + k)) continue;     /* :197-198 */
                 if (use_f64) {
@@ -459,14 +460,36 @@ void oracle_bh_accel(const oracle_tree *t, int n, const float *px, const float *
     int lim = n - (n % group_size);
 #pragma omp parallel for schedule(dynamic, 16) reduction(+ : visits, accepts)
     for (int i = 0; i < lim; i += group_size)
-        bh_group(t, i, group_size, px, py, radius, theta, use_f64, ax, ay, &visits, &accepts);
+        bh_group(t, i, group_size, px, py, radius, theta, use_f64, ax, ay, &visits, &accepts, NULL);
     for (int i = lim; i < n; ++i) ax[i] = ay[i] = 0.0;
     if (counters) { counters[0] = visits; counters[1] = accepts; }
 }
 
+/* The same walk with its counters kept PER GROUP of 8 (index = start / 8): nodes popped (:244-245), nodes accepted
+ * (:266-268) and an order-dependent hash of the accepted node indices.  The compiled reference exports the same three
+ * through oracle/ref_hooks.h (REF_VISIT / REF_ACCEPT), so its vote can be compared group by group. */
+void oracle_bh_group_counters(const oracle_tree *t, int n, const float *px, const float *py, const float *radius,
+                              float theta, int *grp_visits, int *grp_accepts, unsigned long long *grp_hash)
+{
+    int lim = n - (n % VEC_STRIDE);
+    double *ax = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    double *ay = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int i = 0; i < lim; i += VEC_STRIDE) {
+        long long v = 0, a = 0;
+        unsigned long long h = 0;
+        bh_group(t, i, VEC_STRIDE, px, py, radius, theta, 0, ax, ay, &v, &a, &h);
+        grp_visits[i / VEC_STRIDE] = (int)v;
+        grp_accepts[i / VEC_STRIDE] = (int)a;
+        if (grp_hash) grp_hash[i / VEC_STRIDE] = h;
+    }
+    free(ax); free(ay);
+}
+
 /* A7: nsteps of build -> walk -> Euler, benchmark.cpp:354-403 (use_parallel == 0: build only, :359) */
-void oracle_bh_steps(int n, const float *m, float *px, float *py, float *vx, float *vy, const float *radius,
-                     float spread, float theta, float dt, int nsteps, int use_parallel)
+void oracle_bh_steps_counted(int n, const float *m, float *px, float *py, float *vx, float *vy, const float *radius,
+                             float spread, float theta, float dt, int nsteps, int use_parallel,
+                             long long *step_visits, long long *step_accepts)
 {
     oracle_tree *t = oracle_tree_create(n);
     double *ax = (double *)malloc(sizeof(double) * (size_t)n);
@@ -474,12 +497,22 @@ void oracle_bh_steps(int n, const float *m, float *px, float *py, float *vx, flo
     float *fx = (float *)malloc(sizeof(float) * (size_t)n);
     float *fy = (float *)malloc(sizeof(float) * (size_t)n);
     for (int s = 0; s < nsteps; ++s) {
+        long long cnt[2] = {0, 0};
         oracle_tree_build(t, n, spread, m, px, py);
-        if (!use_parallel) continue;
-        oracle_bh_accel(t, n, px, py, radius, theta, 0, VEC_STRIDE, ax, ay, NULL);
-        for (int i = 0; i < n; ++i) { fx[i] = (float)ax[i]; fy[i] = (float)ay[i]; }
-        oracle_euler_f32(n, px, py, vx, vy, fx, fy, dt, 1);
+        if (use_parallel) {
+            oracle_bh_accel(t, n, px, py, radius, theta, 0, VEC_STRIDE, ax, ay, cnt);
+            for (int i = 0; i < n; ++i) { fx[i] = (float)ax[i]; fy[i] = (float)ay[i]; }
+            oracle_euler_f32(n, px, py, vx, vy, fx, fy, dt, 1);
+        }
+        if (step_visits) step_visits[s] = cnt[0];
+        if (step_accepts) step_accepts[s] = cnt[1];
     }
     free(ax); free(ay); free(fx); free(fy);
     oracle_tree_destroy(t);
+}
+
+void oracle_bh_steps(int n, const float *m, float *px, float *py, float *vx, float *vy, const float *radius,
+                     float spread, float theta, float dt, int nsteps, int use_parallel)
+{
+    oracle_bh_steps_counted(n, m, px, py, vx, vy, radius, spread, theta, dt, nsteps, use_parallel, NULL, NULL);
 }

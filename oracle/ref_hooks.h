@@ -35,9 +35,30 @@ typedef struct RefIO {
     void  *tree_pool_out;                       /* raw copy of the node pool (48 B/node) */
     int    tree_pool_cap;                       /* capacity of tree_pool_out in nodes   */
     double *step_ms;                            /* [nsteps] physicsEnd-physicsStart      */
+    /* Barnes-Hut walk counters of the reference's OWN vote (benchmark.cpp:242-276), per group of 8 bodies
+       (index = start_index / 8), accumulated over the steps of the run; NULL => not counted */
+    int   *grp_visits;                          /* nodes popped, benchmark.cpp:244-245   */
+    int   *grp_accepts;                         /* nodes handed to computeForce_kernel, :266-268 */
+    unsigned long long *grp_hash;               /* order-dependent hash of the accepted node indices */
+    long long *step_visits, *step_accepts;      /* [nsteps] totals of each step          */
 } RefIO;
 int ref_benchmark_run(RefIO *p);
 }
+
+/* The walk is a const member function of QuadTree with no RefIO in scope: the counter arrays are reached through
+   file-scope pointers, set from RefIO after the generator (REF_AFTER_INIT).  One group is walked by one thread, so
+   the per-group slots need no atomics. */
+static int *g_ref_grp_visits = nullptr, *g_ref_grp_accepts = nullptr;
+static unsigned long long *g_ref_grp_hash = nullptr;
+static long long g_ref_prev_visits = 0, g_ref_prev_accepts = 0;
+
+/* after node_stack.pop_back(), benchmark.cpp:245 */
+#define REF_VISIT(start) do { if (g_ref_grp_visits) ++g_ref_grp_visits[(start) >> 3]; } while (0)
+/* inside the accept branch, benchmark.cpp:267 */
+#define REF_ACCEPT(start, node)                                                                        \
+    do { if (g_ref_grp_accepts) ++g_ref_grp_accepts[(start) >> 3];                                      \
+         if (g_ref_grp_hash) g_ref_grp_hash[(start) >> 3] =                                             \
+             (g_ref_grp_hash[(start) >> 3] ^ (unsigned long long)(unsigned)(node)) * 1099511628211ull; } while (0)
 
 #define REF_CP_IN(dst, src)  do { if (src) std::memcpy((dst).data(), (src), sizeof(float) * (size_t)p->n); } while (0)
 #define REF_CP_OUT(dst, src) do { if (dst) std::memcpy((dst), (src).data(), sizeof(float) * (size_t)p->n); } while (0)
@@ -51,6 +72,8 @@ int ref_benchmark_run(RefIO *p);
         REF_CP_IN(data.m, p->in_m);     REF_CP_IN(data.posX, p->in_px);    \
         REF_CP_IN(data.posY, p->in_py); REF_CP_IN(data.velX, p->in_vx);    \
         REF_CP_IN(data.velY, p->in_vy); REF_CP_IN(data.radius, p->in_radius); \
+        g_ref_grp_visits = p->grp_visits; g_ref_grp_accepts = p->grp_accepts; g_ref_grp_hash = p->grp_hash; \
+        g_ref_prev_visits = g_ref_prev_accepts = 0;                           \
     } while (0)
 
 /* after tree.build, benchmark.cpp:357 (QuadTree members made public by the recipe) */
@@ -74,7 +97,25 @@ int ref_benchmark_run(RefIO *p);
 /* after physicsEnd, benchmark.cpp:513 */
 #define REF_STEP_TIME(t0, t1)                                                     \
     do { if (p->step_ms) p->step_ms[ref_step] =                                   \
-             std::chrono::duration<double, std::milli>((t1) - (t0)).count(); } while (0)
+             std::chrono::duration<double, std::milli>((t1) - (t0)).count();      \
+         ref_step_totals(p, ref_step); } while (0)
+
+static inline void ref_step_totals(RefIO *p, int step)
+{
+    const int groups = p->n / 8;
+    if (p->step_visits && p->grp_visits) {
+        long long t = 0;
+        for (int g = 0; g < groups; ++g) t += p->grp_visits[g];
+        p->step_visits[step] = t - g_ref_prev_visits;
+        g_ref_prev_visits = t;
+    }
+    if (p->step_accepts && p->grp_accepts) {
+        long long t = 0;
+        for (int g = 0; g < groups; ++g) t += p->grp_accepts[g];
+        p->step_accepts[step] = t - g_ref_prev_accepts;
+        g_ref_prev_accepts = t;
+    }
+}
 
 /* after the loop, before benchmark.cpp:559 */
 #define REF_AFTER_LOOP(data)                                   \

@@ -43,7 +43,11 @@ def bh_case(n, theta, nsteps_final, dt=0.05, want_pool=False):
     out = dict(n=n, seed=SEED, spread=400.0, mass=1000.0, dt=dt, theta=theta, nsteps_final=nsteps_final,
                m=init.m[:1].copy(), radius=init.radius[:1].copy(),
                accX=r1["acc"][0], accY=r1["acc"][1], nodes_used=r1["nodes_used"], root=r1["root"],
-               final_nodes_used=rk["nodes_used"])
+               final_nodes_used=rk["nodes_used"],
+               # the reference's own vote (hooks at benchmark.cpp:245 and :267): per group of 8 for step 1, totals
+               # of every step of the nsteps_final run
+               grp_visits=r1["grp_visits"], grp_accepts=r1["grp_accepts"], grp_hash=r1["grp_hash"],
+               step_visits=rk["step_visits"], step_accepts=rk["step_accepts"])
     out.update({"init_" + k: v for k, v in state(init).items()})
     out.update({"step1_" + k: v for k, v in state(r1["final"]).items()})
     out.update({"final_" + k: v for k, v in state(rk["final"]).items()})

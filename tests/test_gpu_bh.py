@@ -31,7 +31,7 @@ def canonical(pool):
     return np.array(out, dtype=np.float64)
 
 
-def gpu_bh(nb, b, *, theta=1.0, spread=400.0, nsteps=0, dt=0.05, want_tree=False, **kw):
+def gpu_bh(nb, b, *, theta=1.0, spread=400.0, nsteps=0, dt=0.05, want_tree=False, want_groups=False, **kw):
     with nb.NBodySim(b.n, dt=dt, theta=theta, spread=spread, useBarnesHut=True, **kw) as sim:
         sim.upload(*b.arrays())
         if nsteps == 0:
@@ -43,6 +43,8 @@ def gpu_bh(nb, b, *, theta=1.0, spread=400.0, nsteps=0, dt=0.05, want_tree=False
         st = sim.download()
         tree = sim.bh_tree() if want_tree else None
         cnt = sim.bh_counters()
+        if want_groups:
+            cnt = dict(cnt, groups=sim.bh_group_counters())
     return ax, ay, st, tree, cnt
 
 
@@ -78,25 +80,63 @@ def test_accel_equals_oracle_and_matches_reference(nb, O, name):
     assert np.all(ax[lim:] == 0)                                        # tail groups skipped (benchmark.cpp:368)
 
 
-@pytest.mark.parametrize("name", ["bh_n1024_theta1", "bh_n1003_theta1", "bh_n10000_theta1"])
+@pytest.mark.parametrize("name", ["bh_n1024_theta1", "bh_n1003_theta1", "bh_n10000_theta1", "bh_n10000_theta05"])
+def test_vote_equals_the_compiled_reference_group_by_group(nb, O, name):
+    """The GPU walk's accept/open decisions against the COMPILED REFERENCE's own (counters exported at
+    benchmark.cpp:245 / :267 into the goldens), per group of 8 bodies: nodes popped and nodes accepted.  Measured:
+    0 groups differ on every fixture (and 0 of 125 000 at N = 10^6, tools/vote_census.py), so the gate is 0."""
+    g, b = load_golden(O, name)
+    _, _, _, _, cnt = gpu_bh(nb, b, theta=float(g["theta"]), want_groups=True)
+    v, a = cnt["groups"]
+    ng = b.n // 8
+    differ = int(((v[:ng] != g["grp_visits"]) | (a[:ng] != g["grp_accepts"])).sum())
+    assert differ == 0, f"{differ} of {ng} groups vote differently from the compiled reference"
+    assert not v[ng:].any() and not a[ng:].any()                         # N%8 tail group: never walked
+    assert cnt["visits"] == int(g["step_visits"][0]) and cnt["accepts"] == int(g["step_accepts"][0])
+
+
+def test_vote_of_the_reference_on_this_host(nb, O):
+    """The reference's vote goes through vrcpps, whose bits are CPU-vendor specific: the goldens were
+    made on the build container's Intel host.  This runs the compiled reference on THIS box's host CPU, N = 65 536,
+    theta = 1, and compares its per-group counters with the GPU walk's."""
+    if not O.ref_available():
+        pytest.skip("oracle/_ref/libnbody_ref.so not built")
+    n = 65536
+    b = O.init_disc(n, seed=777)
+    r = O.ref_run(n, use_barnes_hut=1, nsteps=1, bodies=b, theta=1.0)
+    _, _, _, _, cnt = gpu_bh(nb, b, want_groups=True)
+    v, a = cnt["groups"]
+    differ = int(((v != r["grp_visits"]) | (a != r["grp_accepts"])).sum())
+    print(f"[vote census on this host] {differ} of {n // 8} groups differ; reference {int(r['step_visits'][0])} visits, "
+          f"GPU {cnt['visits']}")
+    assert differ == 0
+
+
+@pytest.mark.parametrize("name", ["bh_n1024_theta1", "bh_n1003_theta1", "bh_n10000_theta1", "bh_n10000_theta05"])
 def test_short_trajectory_vs_reference(nb, O, name):
     g, b = load_golden(O, name)
     k = int(g["nsteps_final"])
     _, _, st, tree, _ = gpu_bh(nb, b, theta=float(g["theta"]), nsteps=k, dt=float(g["dt"]), want_tree=True)
-    # vs the compiled reference: the vote is discontinuous, so a last-bit difference (its 12-bit rcp) can flip
-    # one node from "accept" to "open" for a group and move those 8 bodies by a per-cent of a step; gate the
-    # bulk tightly and the outliers loosely
+    # vs the compiled reference.  Step 1 takes exactly the reference's votes (test above); afterwards the states
+    # differ by the reference's 12-bit vrcpps in its node kernel (benchmark.cpp:213) and a later vote can flip: one
+    # node goes from "accept" to "open" for a group and moves those 8 bodies by a per-cent of a step.  The goldens
+    # say where that happened (per-step vote totals of the reference vs the oracle's): nowhere in three of the four
+    # fixtures — tight max gates there (measured: 2.7e-6 of the box, 9.1e-5 of vmax) — and from step 3 on at
+    # N = 10 000, theta = 1 (<= 20 of 6.2e5 votes): bulk tight, outliers as measured x 3 (8.4e-4 / 6.9e-3).
+    c = b.copy()
+    sv, sa = O.bh_steps_counted(c, 400.0, float(g["theta"]), float(g["dt"]), k)
+    flipped = not (np.array_equal(sv, g["step_visits"]) and np.array_equal(sa, g["step_accepts"]))
+    assert flipped == (name == "bh_n10000_theta1")
+    pos_gate, vel_gate = (2.5e-3, 2e-2) if flipped else (1e-5, 5e-4)
     for f in ("posX", "posY"):
         d = np.abs(st[f] - g["final_" + f])
-        assert np.median(d) <= 2e-5 * 400.0 and d.max() <= 1e-3 * 400.0
+        assert np.median(d) <= 2e-6 * 400.0 and d.max() <= pos_gate * 400.0, (f, np.median(d), d.max())
     for f in ("velX", "velY"):
         d = np.abs(st[f] - g["final_" + f])
         vmax = np.abs(g["final_" + f]).max()
-        assert np.median(d) <= 2e-4 * vmax and d.max() <= 2e-2 * vmax
+        assert np.median(d) <= 2e-5 * vmax and d.max() <= vel_gate * vmax, (f, np.median(d) / vmax, d.max() / vmax)
     assert abs(len(tree) - int(g["final_nodes_used"])) <= 8             # tree of the LAST step's positions
     # and bit-exact against the oracle's stepping
-    c = b.copy()
-    O.bh_steps(c, 400.0, float(g["theta"]), float(g["dt"]), k)
     for f in ("posX", "posY", "velX", "velY"):
         assert np.array_equal(st[f], getattr(c, f)), f
 
