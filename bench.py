@@ -99,7 +99,8 @@ def main():
     ap.add_argument("--bh-fast-math", action="store_true",
                     help="bh workload: 1-ulp hardware sqrt/rcp in the walk (same votes, terms differ by a few ulp)")
     args = ap.parse_args()
-    if os.environ.get("NBODY_DEBUG"):
+    if os.environ.get("NBODY_DEBUG") or os.environ.get("NBODY_DIST_BACKEND", "nccl") != "nccl":
+        # a stalled rank reports where it stands instead of hanging its launcher (always on in the gloo rehearsal)
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ.get("NBODY_DEBUG_TIMEOUT", "90")), exit=True)
 
@@ -167,10 +168,7 @@ def main():
         barrier()
     force_ms, force_launches = sim.sim.profile_read(0)
     integ_ms, integ_launches = sim.sim.profile_read(1)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sim.reduce_max(elapsed)
 
     if rank == 0 and bh:
         build_ms, build_launches = sim.sim.profile_read(2)
@@ -215,6 +213,7 @@ def main():
             "config": {"workload": f"naive O(N^2) step, N={n}, seeded uniform-(angle,r) disc (benchmark.cpp:317-339, "
                                    f"seed 12345), spread=400 mass=1000 radius=8 dt=0.05",
                        "num_bodies": n, "parallelism": f"i-shard x{world}, all-gather posX/posY per step",
+                       "exchange": ("none" if world == 1 else sim.exchange_mode + ":" + backend),
                        "force_variant": info["force_variant"], "j_slices": info["j_slices"]},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,

@@ -36,10 +36,17 @@ def exchange_slices(tensors, spans, rank, dist, group=None, staging=None):
 
 class ShardedSim:
     """One rank's share of a sharded simulation (naive or Barnes-Hut) on its GPU.  In Barnes-Hut mode every rank
-    rebuilds the (cheap) tree from the gathered positions and walks it for its own targets only."""
+    rebuilds the (cheap) tree from the gathered positions and walks it for its own targets only.
+
+    exchange = "torch" (default): torch.distributed collectives — RCCL ("nccl") on the shared stream, or, for a
+    host-staged backend ("gloo": the CPU tests and the one-GPU rehearsal), this class's own staging through pinned host
+    memory with the collective on CPU tensors.  exchange = "native" (or NBODY_EXCHANGE=native): the library's own
+    in-place ncclAllGather below the C-ABI (nbody_comm_init / nbody_exchange_positions); torch.distributed then only
+    carries the 128-byte RCCL id to the ranks."""
 
     def __init__(self, pkg, num_bodies, rank, world, *, device, dt=0.05, ref_compat=True, dist=None,
-                 useBarnesHut=False, **kw):
+                 useBarnesHut=False, exchange=None, **kw):
+        import os
         import torch
         self.torch, self.dist = torch, dist
         self.rank, self.world, self.n = rank, world, num_bodies
@@ -47,24 +54,50 @@ class ShardedSim:
         self.sim = pkg.NBodySim(num_bodies, dt=dt, useBarnesHut=useBarnesHut, ref_compat=ref_compat, device=device,
                                 shard=self.spans[rank], **kw)
         self.device = torch.device("cuda", device)
-        # One dedicated (non-default) stream carries BOTH the library's kernels and torch's collectives, so the
+        # One dedicated (non-default) stream carries BOTH the library's kernels and the collectives, so the
         # all-gather is ordered after the integrate kernel and before the next force kernel without host syncs.
         # (The default stream's handle is 0, which nbody_set_stream reads as "use the context's own stream".)
         self.stream = torch.cuda.Stream(device=self.device)
         self.sim.set_stream(self.stream.cuda_stream)
         self._pos = None
         self._stage = None
-        # RCCL collectives are stream-ordered device work.  Host-staged backends (gloo: the CPU tests and the
-        # one-GPU rehearsal) copy through pinned memory from a helper thread; torch 2.10/ROCm 7 was seen to stall
-        # there when the helper's stream had to wait on a still-busy compute stream (tools/dist_probe.py), so for
-        # those backends the stream is drained on the host first.
-        self._host_staged = dist is not None and world > 1 and dist.get_backend() != "nccl"
+        self._host = None
+        self.exchange_mode = exchange or os.environ.get("NBODY_EXCHANGE", "torch")
+        if self.exchange_mode not in ("torch", "native"):
+            raise ValueError(f"exchange={self.exchange_mode!r}: expected 'torch' or 'native'")
+        # RCCL collectives are stream-ordered device work.  A host-staged backend (gloo) is NOT handed CUDA tensors:
+        # its CUDA path copies through pinned memory from helper threads on private streams that wait for an event
+        # recorded on the compute stream, and on torch 2.10 / ROCm 7 both ranks were seen to stall inside that wait
+        # (profiles/r2_dist_probe_*.txt).  Host staging needs a host round trip anyway, so this class
+        # does it itself: D2H of the owned slice on the compute stream, stream sync, CPU collective, H2D.
+        self._host_staged = dist is not None and dist.get_backend() != "nccl"
+        if self.exchange_mode == "native" and world > 1:
+            if dist is None:
+                raise ValueError("exchange='native' needs a process group to hand the RCCL id to the ranks")
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8).clone()
+            if dist.get_backend() == "nccl":
+                uid = uid.to(self.device)
+            dist.broadcast(uid, src=0)
+            self.sim.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
 
     def upload(self, m, posX, posY, velX, velY, radius):
         self.sim.upload(m, posX, posY, velX, velY, radius)
         t = self.torch
         self._pos = [t.as_tensor(self.sim.device_array(k), device=self.device) for k in ("posX", "posY")]
-        self._stage = [t.empty_like(p) for p in self._pos] if self.world > 1 else None
+        self.prepare_exchange()
+        return self
+
+    def prepare_exchange(self, force=False):
+        """Staging buffers, once per upload (force: also with one rank — tools/dist_probe.py)."""
+        t = self.torch
+        if (self.world > 1 or force) and self.exchange_mode == "torch":
+            if self._host_staged:
+                self._host = [(t.empty(self.n, dtype=t.float32, pin_memory=True),
+                               t.empty(self.n, dtype=t.float32, pin_memory=True)) for _ in self._pos]
+            else:
+                self._stage = [t.empty_like(p) for p in self._pos]
         return self
 
     def step(self, nsteps=1):
@@ -74,11 +107,36 @@ class ShardedSim:
                 self.exchange()
         return self
 
-    def exchange(self):
+    def exchange(self, force=False):
+        if self.world == 1 and not force:
+            return
+        if self.exchange_mode == "native":
+            self.sim.exchange_positions()                  # in-place ncclAllGather on the context's (= this) stream
+            return
+        t = self.torch
         if self._host_staged:
-            self.stream.synchronize()
-        with self.torch.cuda.stream(self.stream):
+            b, c = self.spans[self.rank]
+            with t.cuda.stream(self.stream):
+                for p, (h, _) in zip(self._pos, self._host):
+                    h[b:b + c].copy_(p[b:b + c], non_blocking=True)
+            self.stream.synchronize()                      # the owned slices are in host memory
+            exchange_slices([h for h, _ in self._host], self.spans, self.rank, self.dist,
+                            staging=[g for _, g in self._host])
+            with t.cuda.stream(self.stream):               # ordered before the next step's kernels
+                for p, (h, _) in zip(self._pos, self._host):
+                    p.copy_(h, non_blocking=True)
+            return
+        with t.cuda.stream(self.stream):
             exchange_slices(self._pos, self.spans, self.rank, self.dist, staging=self._stage)
+
+    def reduce_max(self, value):
+        """max over ranks of a host float (bench.py's timing), on the backend's own kind of tensor."""
+        if self.dist is None or self.world == 1:
+            return float(value)
+        t = self.torch
+        x = t.tensor([value], dtype=t.float64, device="cpu" if self._host_staged else self.device)
+        self.dist.all_reduce(x, op=self.dist.ReduceOp.MAX)
+        return float(x.item())
 
     def sync(self):
         self.stream.synchronize()
@@ -88,6 +146,7 @@ class ShardedSim:
 
     def close(self):
         self._pos = None
+        self._host = None
         self.sim.close()
 
 

@@ -13,9 +13,8 @@ import __graft_entry__ as entry  # noqa: E402
 
 
 def main():
-    if os.environ.get("NBODY_DEBUG"):
-        import faulthandler
-        faulthandler.dump_traceback_later(40, exit=True)
+    import faulthandler
+    faulthandler.dump_traceback_later(60, exit=True)     # a stalled rank reports where it stands and ends
     n, nsteps, bh = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     out = sys.argv[4]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])

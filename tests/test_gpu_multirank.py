@@ -3,9 +3,10 @@ bench.py uses (nbody_amd.sharded.ShardedSim: shard plan from the C-ABI, library 
 torch stream, staged all-gather).  The test box has one GPU, so the ranks share it and talk over `gloo`
 (NBODY_DIST_BACKEND); on the 8-GPU node the only difference is backend="nccl" (RCCL) and one device per rank.
 
-Both paths are rehearsed.  With a host-staged backend (gloo) ShardedSim drains its stream before each exchange:
-gloo's helper thread stalled when its private stream had to wait on a still-busy compute stream (reproduced in ONE
-process by tools/dist_probe.py; the RCCL path, stream-ordered device work, ran the same probe cleanly)."""
+With a host-staged backend (gloo) ShardedSim stages the owned slices through pinned host memory itself and runs the
+collective on CPU tensors: gloo's own CUDA path stalled here (tools/dist_probe.py).  Every rank arms a
+faulthandler watchdog, and the launcher's time limit is below the GPU box's 180-s silence limit, so a stall ends as
+a FAILED test that shows the ranks' stacks instead of a killed run."""
 import os
 import socket
 import subprocess
@@ -16,6 +17,14 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def launch(cmd, env, timeout, **kw):
+    try:
+        return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, **kw)
+    except subprocess.TimeoutExpired as e:
+        out = (e.stdout or b"")[-1500:], (e.stderr or b"")[-4000:]
+        pytest.fail(f"ranks still running after {timeout} s\nstdout: {out[0]!r}\nstderr: {out[1]!r}")
 
 
 def free_port():
@@ -31,7 +40,7 @@ def test_sharded_ranks_equal_single_context(nb, O, tmp_path, world, n, bh):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "multirank_worker.py"), str(n),
            str(nsteps), str(bh), str(tmp_path)]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
+    r = launch(cmd, env, 120)
     assert r.returncode == 0, r.stderr[-3000:]
     b = O.init_disc(n, seed=77)
     with nb.NBodySim(n, dt=0.05, useBarnesHut=bool(bh)) as sim:
@@ -54,7 +63,7 @@ def test_bench_two_ranks_prints_one_json_line(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--bodies", "131072"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200, cwd=str(tmp_path))
+    r = launch(cmd, env, 150, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1

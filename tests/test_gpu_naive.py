@@ -226,6 +226,29 @@ def test_n1m_exact_symmetries(nb, O):
     assert e.max() <= 5e-6, e.max()
 
 
+def test_config3_one_rank_of_eight_launch_geometry(nb, O):
+    """BASELINE config 3 as ONE rank of the 8 sees it: N = 2^20 sources, the rank's 131 072 owned targets starting at
+    i_begin != 0, which plan_force cuts into 64 j-slices of 16 384 sources (the big-tile path, not the small-tile one
+    the N <= 8192 shard tests take).  Sampled f64 check of the shard, agreement with the unsharded launch (different
+    j-slicing => different fp32 summation order, measured 6e-7), zeros outside the shard.  benchmark.cpp:420-478."""
+    n = 1 << 20
+    b = O.init_disc(n, seed=12345)
+    beg, cnt = nb.shard_range(n, 8, 3)
+    assert (beg, cnt) == (3 * (n // 8), n // 8)
+    ax, ay, _, info = run_gpu(nb, b, shard=(beg, cnt))
+    assert info["j_slices"] == 64 and info["blocks"] == cnt // 1024
+    idx = (beg + np.linspace(0, cnt - 1, 256)).astype(np.int32)
+    rx, ry = O.naive_accel_f64_subset(b, idx)
+    e = rel_err(ax[idx], ay[idx], rx, ry)
+    assert e.max() <= TOL_F64, e.max()
+    fx, fy, _, finfo = run_gpu(nb, b)
+    assert finfo["j_slices"] == 8
+    e = rel_err(ax[beg:beg + cnt], ay[beg:beg + cnt], fx[beg:beg + cnt], fy[beg:beg + cnt])
+    assert e.max() <= 2e-6, e.max()
+    outside = np.ones(n, bool); outside[beg:beg + cnt] = False
+    assert not ax[outside].any() and not ay[outside].any()
+
+
 def test_diagnostics_vs_oracle(nb, O):
     b = O.init_disc(4096, seed=31)
     b.posX *= 0.2; b.posY *= 0.2            # both potential branches populated
