@@ -146,6 +146,9 @@ void *nbody_device_ptr(nbody_ctx *ctx, int32_t which);
 int nbody_profile_enable(nbody_ctx *ctx, int32_t on);
 int nbody_profile_read(nbody_ctx *ctx, int32_t which, double *total_ms, int64_t *launches);
 int nbody_profile_reset(nbody_ctx *ctx);
+/* Duration in ms of every launch of that class since the last reset, in launch order: copies at most cap values,
+   returns how many there are (< 0: error).  Lets a harness report min/median/max, not only the mean. */
+int64_t nbody_profile_samples(nbody_ctx *ctx, int32_t which, float *out_ms, int64_t cap);
 
 /* Introspection for tests/bench: which force variant upload selected (1..4), grid geometry. */
 int nbody_get_info(nbody_ctx *ctx, int32_t *force_variant, int32_t *j_slices, int32_t *blocks);

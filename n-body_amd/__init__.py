@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "nbody_upload", "nbody_step", "nbody_compute_accel", "nbody_sync", "nbody_download", "nbody_frame_publish",
     "nbody_frame_acquire", "nbody_comm_unique_id", "nbody_comm_init", "nbody_exchange_positions", "nbody_get_accel",
     "nbody_diagnostics", "nbody_device_ptr", "nbody_profile_enable", "nbody_profile_read",
-    "nbody_profile_reset", "nbody_get_info", "nbody_bh_tree_nodes", "nbody_bh_counters",
+    "nbody_profile_reset", "nbody_profile_samples", "nbody_get_info", "nbody_bh_tree_nodes", "nbody_bh_counters",
     "nbody_bh_group_counters",
     "nbody_last_error", "nbody_abi_version",
 )
@@ -80,6 +80,8 @@ def lib():
         L.nbody_profile_enable.argtypes = [C.c_void_p, C.c_int32]
         L.nbody_profile_read.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.nbody_profile_reset.argtypes = [C.c_void_p]
+        L.nbody_profile_samples.argtypes = [C.c_void_p, C.c_int32, _f32p, C.c_int64]
+        L.nbody_profile_samples.restype = C.c_int64
         L.nbody_get_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 3
         L.nbody_bh_tree_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.nbody_bh_tree_nodes.restype = C.c_int64
@@ -237,6 +239,15 @@ class NBodySim:
         ms, cnt = C.c_double(), C.c_int64()
         _check(lib().nbody_profile_read(self._h, which, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def profile_samples(self, which=0):
+        """Per-launch durations (ms) of that kernel class since the last profile_reset."""
+        n = lib().nbody_profile_samples(self._h, which, None, 0)
+        if n < 0:
+            raise NBodyError(int(n), lib().nbody_last_error().decode())
+        out = np.zeros(max(int(n), 1), np.float32)
+        lib().nbody_profile_samples(self._h, which, _ptr(out), int(n))
+        return out[:int(n)]
 
     def info(self):
         v, s, b = C.c_int32(), C.c_int32(), C.c_int32()

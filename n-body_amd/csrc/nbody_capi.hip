@@ -50,6 +50,7 @@ struct Profiler {
     size_t used[3] = {0, 0, 0};
     double total_ms[3] = {0, 0, 0};
     int64_t launches[3] = {0, 0, 0};
+    std::vector<float> samples[3];    // duration of every launch since the last reset (nbody_profile_samples)
 };
 
 constexpr int kMaxSlices = 64;
@@ -132,6 +133,7 @@ int profile_begin(nbody_ctx* ctx, int cls, EventPair** out)
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, p.pool[cls][i].a, p.pool[cls][i].b));
             p.total_ms[cls] += ms;
+            p.samples[cls].push_back(ms);
         }
         p.used[cls] = 0;
     }
@@ -841,6 +843,7 @@ int nbody_profile_read(nbody_ctx* ctx, int32_t which, double* total_ms, int64_t*
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, p.pool[which][i].a, p.pool[which][i].b));
         p.total_ms[which] += ms;
+        p.samples[which].push_back(ms);
     }
     p.used[which] = 0;
     if (total_ms) *total_ms = p.total_ms[which];
@@ -853,8 +856,20 @@ int nbody_profile_reset(nbody_ctx* ctx)
     if (!ctx) return fail(NBODY_ERR_INVALID, "nbody_profile_reset: null context");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (int k = 0; k < 3; ++k) { ctx->prof.used[k] = 0; ctx->prof.total_ms[k] = 0; ctx->prof.launches[k] = 0; }
+    for (int k = 0; k < 3; ++k) { ctx->prof.used[k] = 0; ctx->prof.total_ms[k] = 0; ctx->prof.launches[k] = 0; ctx->prof.samples[k].clear(); }
     return NBODY_OK;
+}
+
+int64_t nbody_profile_samples(nbody_ctx* ctx, int32_t which, float* out_ms, int64_t cap)
+{
+    double total = 0;
+    int64_t launches = 0;
+    const int rc = nbody_profile_read(ctx, which, &total, &launches);     // drains the outstanding event pairs
+    if (rc) return rc;
+    const auto& v = ctx->prof.samples[which];
+    const int64_t k = (int64_t)v.size() < cap ? (int64_t)v.size() : cap;
+    if (out_ms && k > 0) std::memcpy(out_ms, v.data(), sizeof(float) * (size_t)k);
+    return (int64_t)v.size();
 }
 
 int nbody_get_info(nbody_ctx* ctx, int32_t* force_variant, int32_t* j_slices, int32_t* blocks)
