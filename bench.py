@@ -27,6 +27,69 @@ PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/c
 FLOP_PER_INTERACTION = 20     # BASELINE.json convention
 
 
+class ClockSampler:
+    """Shader clock and socket power while the timed region runs, read through the amdsmi library that ships with
+    ROCm (gpu_metrics: one gfx clock per XCD).  The chip runs this kernel at its ~1.4 kW power cap, so the clock it
+    holds — not the kernel — is what moves ms/step between boxes and runs; with it in the JSON line a slow run
+    explains itself.  Best effort: any failure leaves `clock` null."""
+
+    def __init__(self, gpu_index, period_s=0.01):
+        self.rows, self.err, self._stop = [], None, False
+        self.period = period_s
+        try:
+            import threading
+            for p in ("/opt/rocm/share/amd_smi", "/opt/rocm/libexec/amdsmi_cli"):
+                if os.path.isdir(p) and p not in sys.path:
+                    sys.path.append(p)
+            import amdsmi
+            self.smi = amdsmi
+            amdsmi.amdsmi_init()
+            hs = amdsmi.amdsmi_get_processor_handles()
+            self.h = hs[gpu_index if gpu_index < len(hs) else 0]
+            self._read()                                  # fail here, not in the thread
+            self.th = threading.Thread(target=self._run, daemon=True)
+        except Exception as e:                            # noqa: BLE001 (instrumentation must never stop the bench)
+            self.err, self.th = f"{type(e).__name__}: {e}"[:200], None
+
+    def _read(self):
+        m = self.smi.amdsmi_get_gpu_metrics_info(self.h)
+        clk = [c for c in (m.get("current_gfxclks") or []) if isinstance(c, (int, float)) and 0 < c < 10000]
+        pw = m.get("current_socket_power")
+        if not isinstance(pw, (int, float)) or pw <= 0 or pw > 10000:
+            pw = m.get("average_socket_power")
+        return (time.perf_counter(), float(np.mean(clk)) if clk else float("nan"),
+                float(pw) if isinstance(pw, (int, float)) else float("nan"))
+
+    def _run(self):
+        while not self._stop:
+            try:
+                self.rows.append(self._read())
+            except Exception as e:                        # noqa: BLE001
+                self.err = f"{type(e).__name__}: {e}"[:200]
+                return
+            time.sleep(self.period)
+
+    def start(self):
+        if self.th:
+            self.th.start()
+        return self
+
+    def stop(self, t0, t1):
+        """Summary of the samples taken inside [t0, t1] (perf_counter times)."""
+        self._stop = True
+        if self.th:
+            self.th.join(timeout=2.0)
+        rows = [r for r in self.rows if t0 <= r[0] <= t1 and r[1] == r[1]]
+        if not rows:
+            return {"gfx_mhz": None, "note": self.err or "no samples inside the timed region"}
+        clk = np.array([r[1] for r in rows]); pw = np.array([r[2] for r in rows])
+        out = {"gfx_mhz": float(np.median(clk)), "gfx_mhz_min": float(clk.min()), "gfx_mhz_max": float(clk.max()),
+               "samples": len(rows), "source": "amdsmi gpu_metrics current_gfxclks (mean over XCDs), sampled in the timed region"}
+        if np.isfinite(pw).any():
+            out["socket_power_w"] = float(np.nanmedian(pw))
+        return out
+
+
 def cpu_baseline(budget_s=12.0):
     """The reference's own OpenMP+AVX2 naive loop (oracle/_ref, built from /root/reference/benchmark.cpp by
     oracle/build_ref.sh) timed on this host: N=65536, as many steps as fit the budget (>= 3)."""
@@ -156,11 +219,14 @@ def main():
     # Barnes-Hut: the timed region runs the captured hipGraph (no event pairs inside a capture); the per-kernel
     # figures come from one eager step (step 1 of the same state) AFTER it.
     sim.sim.profile(not bh).profile_reset()
+    sampler = ClockSampler(local_rank).start() if rank == 0 else None
     barrier()
     t0 = time.perf_counter()
     sim.step(args.steps)
     barrier()
-    elapsed = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    clock = sampler.stop(t0, t1) if sampler else None
     if bh:
         sim.upload(*bodies)
         sim.sim.profile(True).profile_reset()
@@ -186,7 +252,7 @@ def main():
                        "num_bodies": n, "parallelism": f"tree replicated, walk i-sharded x{world}",
                        "arithmetic": "hardware sqrt/rcp, exact vote" if args.bh_fast_math else "IEEE (bit-identical to the oracle)"},
             "roofline": {"bound": "hbm", "achieved": walk_gbs, "peak": 8000.0, "unit": "GB/s", "frac": walk_gbs / 8000.0,
-                         "traffic": None, "kernel": "bh_walk_kernel", "kernel_ms": walk_ms,
+                         "traffic": None, "kernel": "bh_walk_kernel", "kernel_ms": walk_ms, "clock": clock,
                          "build_ms": build_ms / max(1, build_launches), "launches": int(force_launches),
                          "node_visits_step1": int(cnt["visits"]), "accepted_nodes_step1": int(cnt["accepts"]),
                          "note": "tree walk priced in bytes (24 B per group-visit of rank 0's launch, SURVEY.md §8d: no flop "
@@ -205,6 +271,11 @@ def main():
         k_ms = force_ms / max(1, force_launches)
         achieved = FLOP_PER_INTERACTION * float(my_targets) * n / (k_ms * 1e-3) / 1e12
         info = sim.sim.info()
+        k_all = sim.sim.profile_samples(0)
+        # The peak assumes 2.4 GHz; the chip holds less at its power cap.  frac_at_clock prices the same launch
+        # against the peak AT THE CLOCK IT RAN AT, which separates "slow box" from "slow kernel".
+        mhz = clock.get("gfx_mhz") if clock else None
+        frac_at_clock = achieved / (PEAK_FP32_TFLOPS * mhz / 2400.0) if mhz else None
         line = {
             "metric": "G body-body interactions/s, N=1M naive step",
             "value": value, "unit": "G interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -218,6 +289,10 @@ def main():
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
                          "kernel": "force_naive_kernel", "kernel_ms": k_ms, "launches": int(force_launches),
+                         "kernel_ms_min": float(k_all.min()) if len(k_all) else None,
+                         "kernel_ms_median": float(np.median(k_all)) if len(k_all) else None,
+                         "kernel_ms_max": float(k_all.max()) if len(k_all) else None,
+                         "clock": clock, "frac_at_measured_clock": frac_at_clock,
                          "note": "FP32 vector (no MFMA: elementwise-transcendental pair loop); algorithmic flop = "
                                  "20 x owned targets x N sources per launch (rank 0); integrate_kernel "
                                  f"{integ_ms / max(1, integ_launches) * 1e3:.1f} us/launch"},

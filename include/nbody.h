@@ -167,6 +167,19 @@ int nbody_bh_counters(nbody_ctx *ctx, int64_t out[2]);
    at benchmark.cpp:245 (node popped) and :267 (node accepted).  Syncs. */
 int nbody_bh_group_counters(nbody_ctx *ctx, int32_t *visits, int32_t *accepts);
 
+/* NO COUNTERPART IN THE REFERENCE.  The force phase for callers that cannot allocate device memory: code under HIP
+   graph capture, tight serving loops, harnesses that forbid hipMalloc.  It is nbody_compute_accel + nbody_get_accel
+   of a context with ref_compat = 1 and force_variant = 4 (exact-general formula: any mass, any radius) — same
+   kernels, same launch plan, bit-identical accelerations — but stateless: every array is a DEVICE pointer of length
+   num_bodies owned by the caller (inputs m, posX, posY, radius; outputs accX, accY; the N%8 tail gets 0,
+   benchmark.cpp:423), work is enqueued on hip_stream (NULL = the null stream) of the CURRENT device and the call
+   returns without synchronising.  It calls no hipMalloc/hipFree: the j-slice partial sums and the per-body clamp
+   constants live in a 33.8 MB array that the library holds statically on every GPU it runs on.  Limits:
+   num_bodies <= 65536 (NBODY_ERR_INVALID beyond); all calls on one GPU share that array, so calls that overlap on
+   one GPU (different streams, different threads) race — serialise them. */
+int nbody_accel_noalloc(int32_t num_bodies, const float *dev_m, const float *dev_posX, const float *dev_posY,
+                        const float *dev_radius, float *dev_accX, float *dev_accY, void *hip_stream);
+
 const char *nbody_last_error(void); /* thread-local, never NULL */
 int nbody_abi_version(void);
 

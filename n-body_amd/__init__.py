@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "nbody_frame_acquire", "nbody_comm_unique_id", "nbody_comm_init", "nbody_exchange_positions", "nbody_get_accel",
     "nbody_diagnostics", "nbody_device_ptr", "nbody_profile_enable", "nbody_profile_read",
     "nbody_profile_reset", "nbody_profile_samples", "nbody_get_info", "nbody_bh_tree_nodes", "nbody_bh_counters",
-    "nbody_bh_group_counters",
+    "nbody_bh_group_counters", "nbody_accel_noalloc",
     "nbody_last_error", "nbody_abi_version",
 )
 
@@ -87,6 +87,7 @@ def lib():
         L.nbody_bh_tree_nodes.restype = C.c_int64
         L.nbody_bh_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.nbody_bh_group_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.nbody_accel_noalloc.argtypes = [C.c_int32] + [C.c_void_p] * 7
         L.nbody_last_error.restype = C.c_char_p
         L.nbody_abi_version.restype = C.c_int
         _lib = L
@@ -116,6 +117,14 @@ def comm_unique_id():
     buf = C.create_string_buffer(128)
     _check(lib().nbody_comm_unique_id(buf))
     return buf.raw
+
+
+def accel_noalloc(num_bodies, dev_m, dev_posX, dev_posY, dev_radius, dev_accX, dev_accY, hip_stream=None):
+    """nbody_accel_noalloc: all arrays are raw DEVICE addresses (ints) owned by the caller; enqueues on hip_stream of
+    the current device and returns.  Allocates nothing (include/nbody.h)."""
+    _check(lib().nbody_accel_noalloc(int(num_bodies), *[C.c_void_p(int(p)) for p in
+                                                        (dev_m, dev_posX, dev_posY, dev_radius, dev_accX, dev_accY)],
+                                     C.c_void_p(hip_stream or 0)))
 
 
 def _as_f32(a, n, name):

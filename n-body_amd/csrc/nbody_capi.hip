@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <utility>
 #include <vector>
@@ -304,15 +305,36 @@ int enqueue_bh_walk(nbody_ctx* ctx, int advance)
 
 // Geometry of the force launch: enough workgroups to fill 256 CUs several times over, so that the
 // dispatcher can even out the load (one workgroup = 4 waves; 256 CUs x 4 SIMDs want >= 2 waves each).
+struct ForcePlan { int k, blocks_x, tile, j_per_slice, slices; };
+
+// n sources, nt targets.  k_req / slices_req / tile_req: 0 = derive (the developer knobs below set them).
+ForcePlan make_force_plan(int n, int nt, int variant, int max_slices, int k_req = 0, int slices_req = 0, int tile_req = 0)
+{
+    ForcePlan p{};
+    const int big = big_tile_of(variant ? variant : (int)kScaled);
+    p.k = k_req ? k_req : (nt >= (1 << 15) ? 4 : 2);
+    p.blocks_x = (nt + kBlock * p.k - 1) / (kBlock * p.k);
+    if (p.blocks_x < 1) p.blocks_x = 1;
+    int want = slices_req ? slices_req : (8192 + p.blocks_x - 1) / p.blocks_x;   // aim for >= 8192 workgroups (measured: tools/sweep.py)
+    if (want > max_slices) want = max_slices;
+    // tile: the big one unless that leaves fewer slices than wanted
+    p.tile = tile_req ? tile_req : (((n + want - 1) / want >= big) ? big : kTileSmall);
+    const int max_slices_by_n = (n + p.tile - 1) / p.tile;
+    if (want > max_slices_by_n) want = max_slices_by_n;
+    if (want < 1) want = 1;
+    p.j_per_slice = ((n + want - 1) / want + p.tile - 1) / p.tile * p.tile;
+    p.slices = (n + p.j_per_slice - 1) / p.j_per_slice;
+    return p;
+}
+
 void plan_force(nbody_ctx* ctx)
 {
     const int n = ctx->cfg.num_bodies;
     const int nt = ctx->i_end - ctx->i_begin;
-    const int big = big_tile_of(ctx->variant ? ctx->variant : (int)kScaled);
-    int k = nt >= (1 << 15) ? 4 : 2;
-    int want = 0;                                  // 0 = derive from the workgroup target
+    const int variant = ctx->variant ? ctx->variant : (int)kScaled;
     // developer tuning knobs (not part of the ABI): NBODY_FORCE_K = 2|4, NBODY_FORCE_SLICES = 1..64,
     // NBODY_FORCE_TILE = small|big
+    int k = 0, want = 0, tile = 0;
     if (const char* e = std::getenv("NBODY_FORCE_K")) {
         const int v = std::atoi(e);
         if (v == 2 || v == 4) k = v;
@@ -321,21 +343,13 @@ void plan_force(nbody_ctx* ctx)
         const int v = std::atoi(e);
         if (v >= 1 && v <= kMaxSlices) want = v;
     }
-    ctx->k_per_lane = k;
-    ctx->blocks_x = (nt + kBlock * k - 1) / (kBlock * k);
-    if (ctx->blocks_x < 1) ctx->blocks_x = 1;
-    if (want == 0) want = (8192 + ctx->blocks_x - 1) / ctx->blocks_x;   // aim for >= 8192 workgroups (measured: tools/sweep.py)
-    if (want > kMaxSlices) want = kMaxSlices;
-    // tile: the big one unless that leaves fewer slices than wanted
-    int tile = ((n + want - 1) / want >= big) ? big : kTileSmall;
-    if (const char* e = std::getenv("NBODY_FORCE_TILE")) tile = (e[0] == 's') ? kTileSmall : big;
-    const int max_slices_by_n = (n + tile - 1) / tile;
-    if (want > max_slices_by_n) want = max_slices_by_n;
-    if (want < 1) want = 1;
-    const int jps = ((n + want - 1) / want + tile - 1) / tile * tile;
-    ctx->tile = tile;
-    ctx->j_per_slice = jps;
-    ctx->slices = (n + jps - 1) / jps;
+    if (const char* e = std::getenv("NBODY_FORCE_TILE")) tile = (e[0] == 's') ? kTileSmall : big_tile_of(variant);
+    const ForcePlan p = make_force_plan(n, nt, variant, kMaxSlices, k, want, tile);
+    ctx->k_per_lane = p.k;
+    ctx->blocks_x = p.blocks_x;
+    ctx->tile = p.tile;
+    ctx->j_per_slice = p.j_per_slice;
+    ctx->slices = p.slices;
 }
 
 }  // namespace
@@ -946,6 +960,94 @@ int nbody_bh_group_counters(nbody_ctx* ctx, int32_t* visits, int32_t* accepts)
     const size_t nb = sizeof(int) * (size_t)((ctx->cfg.num_bodies + 7) / 8);
     HIP_TRY(hipMemcpy(visits, ctx->bh.grp_visits, nb, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(accepts, ctx->bh.grp_accepts, nb, hipMemcpyDeviceToHost));
+    return NBODY_OK;
+}
+
+// ---- nbody_accel_noalloc: the force phase for callers that cannot allocate (no counterpart in the reference) ----
+// The j-slice partial rows and the per-body clamp constants, which a context keeps in hipMalloc'ed buffers, live
+// here in a file-scope device array.  `scratch` is a HOST-SIDE STAND-IN for that array: host code never passes the
+// name to a kernel or a memset; it resolves the device address once per device (hipGetSymbolAddress) and uses that.
+constexpr int kNoAllocMaxBodies = 65536;
+constexpr size_t kNoAllocScratchFloats = (size_t)kNoAllocMaxBodies * (2 * kMaxSlices + 1);   // pax + pay rows, c[]: 33.8 MB
+constexpr int kNoAllocMaxDevices = 64;
+
+static __device__ __align__(256) float scratch[kNoAllocScratchFloats];
+
+namespace {
+
+// c[i] = R_i^2: the exact-general variant's clamp constant (what nbody_upload derives on the host for a context)
+__global__ __launch_bounds__(256) void noalloc_prepare_kernel(const float* __restrict__ radius, float* __restrict__ c, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const float r = radius[i]; c[i] = r * r; }
+}
+
+float* g_scratch_ptr[kNoAllocMaxDevices] = {};
+std::mutex g_scratch_mutex;
+
+// the device address of `scratch` on the CURRENT device (each GPU holds its own copy at its own address)
+int noalloc_scratch(int dev, float** out)
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(NBODY_ERR_HIP, "nbody_accel_noalloc: hipGetSymbolAddress returned a null address");
+        g_scratch_ptr[dev] = static_cast<float*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return NBODY_OK;
+}
+
+}  // namespace
+
+int nbody_accel_noalloc(int32_t num_bodies, const float* dev_m, const float* dev_posX, const float* dev_posY,
+                        const float* dev_radius, float* dev_accX, float* dev_accY, void* hip_stream)
+{
+    if (!dev_m || !dev_posX || !dev_posY || !dev_radius || !dev_accX || !dev_accY)
+        return fail(NBODY_ERR_INVALID, "nbody_accel_noalloc: null argument");
+    if (num_bodies < 1 || num_bodies > kNoAllocMaxBodies)
+        return fail(NBODY_ERR_INVALID, "nbody_accel_noalloc: num_bodies=%d outside [1, %d] (the static scratch array holds "
+                                       "the partial rows of at most %d bodies; use a context for more)",
+                    num_bodies, kNoAllocMaxBodies, kNoAllocMaxBodies);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kNoAllocMaxDevices) return fail(NBODY_ERR_INVALID, "nbody_accel_noalloc: device ordinal %d", dev);
+    float* sp = nullptr;
+    int rc = noalloc_scratch(dev, &sp);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const int n = num_bodies;
+    const int lim = n - n % 8;                                   // benchmark.cpp:423: the N%8 tail is never a target
+    if (lim > 0) {
+        const int stride = ((lim + 63) / 64) * 64;
+        const ForcePlan p = make_force_plan(n, lim, kExact, kMaxSlices);
+        if ((size_t)n + 2 * (size_t)p.slices * stride > kNoAllocScratchFloats)
+            return fail(NBODY_ERR_INVALID, "nbody_accel_noalloc: internal: plan exceeds the scratch array");
+        float* c = sp;                                           // [n]
+        float* pax = sp + kNoAllocMaxBodies;                     // [slices][stride]
+        float* pay = pax + (size_t)kMaxSlices * kNoAllocMaxBodies;
+        // nothing in the scratch array has to start at zero: c[0..n) and every partial row [0..slices) x [0..lim)
+        // are written in full by this call before they are read, so the previous call's contents never show
+        noalloc_prepare_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(dev_radius, c, n);
+        ForceArgs a{};
+        a.px = dev_posX; a.py = dev_posY; a.m = dev_m; a.c = c;
+        a.pax = pax; a.pay = pay;
+        a.n = n; a.i_begin = 0; a.i_end = lim; a.i_stride = stride;
+        a.j_per_slice = p.j_per_slice;
+        a.pre_scale = 1.0f; a.uni_c = 0.0f; a.out_scale = 1.0f;
+        launch_force_k<kExact>(p.k, p.tile, a, dim3(p.blocks_x, p.slices), s);
+        IntegrateArgs g{};
+        g.pax = pax; g.pay = pay; g.ax = dev_accX; g.ay = dev_accY;
+        g.i_begin = 0; g.i_end = lim; g.i_stride = stride; g.slices = p.slices;
+        g.dt = 0.0f; g.advance = 0;
+        integrate_kernel<<<dim3((lim + 255) / 256), dim3(256), 0, s>>>(g);
+    }
+    if (lim < n) {
+        HIP_TRY(hipMemsetAsync(dev_accX + lim, 0, sizeof(float) * (size_t)(n - lim), s));
+        HIP_TRY(hipMemsetAsync(dev_accY + lim, 0, sizeof(float) * (size_t)(n - lim), s));
+    }
+    HIP_TRY(hipGetLastError());
     return NBODY_OK;
 }
 
