@@ -28,17 +28,19 @@ FLOP_PER_INTERACTION = 20     # BASELINE.json convention
 
 
 class ClockSampler:
-    """Shader clock and socket power while the timed region runs, read through the amdsmi library that ships with
-    ROCm (gpu_metrics: one gfx clock per XCD).  The chip runs this kernel at its ~1.4 kW power cap, so the clock it
-    holds — not the kernel — is what moves ms/step between boxes and runs; with it in the JSON line a slow run
-    explains itself.  Best effort: any failure leaves `clock` null."""
+    """Shader clock and socket power under the benchmark's load, read through the amdsmi library that ships with ROCm
+    (gpu_metrics: one gfx clock per XCD).  The chip runs the pair kernel at its ~1.4 kW power cap, so the clock it holds
+    — not the kernel — is what moves ms/step between boxes and runs; with it in the JSON line a slow run explains itself.
+    On this pool the driver refreshes gpu_metrics ONCE PER SECOND (tools/clock_probe2.py): the thread polls every 10 ms
+    and keeps one row per refresh (a change of system_clock_counter), stamped with the time it was first seen.
+    Best effort: any failure leaves the clock null."""
 
     def __init__(self, gpu_index, period_s=0.01):
         self.rows, self.err, self._stop = [], None, False
         self.period = period_s
         try:
             import threading
-            for p in ("/opt/rocm/share/amd_smi", "/opt/rocm/libexec/amdsmi_cli"):
+            for p in ("/opt/rocm/share/amd_smi",):
                 if os.path.isdir(p) and p not in sys.path:
                     sys.path.append(p)
             import amdsmi
@@ -46,7 +48,7 @@ class ClockSampler:
             amdsmi.amdsmi_init()
             hs = amdsmi.amdsmi_get_processor_handles()
             self.h = hs[gpu_index if gpu_index < len(hs) else 0]
-            self._read()                                  # fail here, not in the thread
+            self._last = self._read()[1]                  # fail here, not in the thread
             self.th = threading.Thread(target=self._run, daemon=True)
         except Exception as e:                            # noqa: BLE001 (instrumentation must never stop the bench)
             self.err, self.th = f"{type(e).__name__}: {e}"[:200], None
@@ -55,18 +57,21 @@ class ClockSampler:
         m = self.smi.amdsmi_get_gpu_metrics_info(self.h)
         clk = [c for c in (m.get("current_gfxclks") or []) if isinstance(c, (int, float)) and 0 < c < 10000]
         pw = m.get("current_socket_power")
-        if not isinstance(pw, (int, float)) or pw <= 0 or pw > 10000:
-            pw = m.get("average_socket_power")
-        return (time.perf_counter(), float(np.mean(clk)) if clk else float("nan"),
-                float(pw) if isinstance(pw, (int, float)) else float("nan"))
+        act = m.get("average_gfx_activity")
+        return (time.perf_counter(), m.get("system_clock_counter"), float(np.mean(clk)) if clk else float("nan"),
+                float(pw) if isinstance(pw, (int, float)) else float("nan"),
+                float(act) if isinstance(act, (int, float)) else float("nan"))
 
     def _run(self):
         while not self._stop:
             try:
-                self.rows.append(self._read())
+                r = self._read()
             except Exception as e:                        # noqa: BLE001
                 self.err = f"{type(e).__name__}: {e}"[:200]
                 return
+            if r[1] != self._last:                        # a fresh table
+                self._last = r[1]
+                self.rows.append(r)
             time.sleep(self.period)
 
     def start(self):
@@ -75,16 +80,20 @@ class ClockSampler:
         return self
 
     def stop(self, t0, t1):
-        """Summary of the samples taken inside [t0, t1] (perf_counter times)."""
+        """Summary of the refreshes first seen inside [t0, t1] (perf_counter times; the GPU was under this load
+        without a break from t0 on)."""
         self._stop = True
         if self.th:
             self.th.join(timeout=2.0)
-        rows = [r for r in self.rows if t0 <= r[0] <= t1 and r[1] == r[1]]
+        # a refresh describes the second BEFORE it (its average_gfx_activity says how much of that second was busy):
+        # keep the ones whose whole second lay under the load
+        rows = [r for r in self.rows if t0 + 1.0 <= r[0] <= t1 and r[2] == r[2] and not (r[4] < 99.0)]
         if not rows:
-            return {"gfx_mhz": None, "note": self.err or "no samples inside the timed region"}
-        clk = np.array([r[1] for r in rows]); pw = np.array([r[2] for r in rows])
+            return {"gfx_mhz": None, "note": self.err or "no gpu_metrics refresh covers a fully loaded second (it refreshes once per second): run more steps"}
+        clk = np.array([r[2] for r in rows]); pw = np.array([r[3] for r in rows])
         out = {"gfx_mhz": float(np.median(clk)), "gfx_mhz_min": float(clk.min()), "gfx_mhz_max": float(clk.max()),
-               "samples": len(rows), "source": "amdsmi gpu_metrics current_gfxclks (mean over XCDs), sampled in the timed region"}
+               "snapshots": len(rows),
+               "source": "amdsmi gpu_metrics current_gfxclks, mean over the XCDs; one snapshot per 1-s refresh, kept when its whole second was under this load (gfx activity >= 99 %)"}
         if np.isfinite(pw).any():
             out["socket_power_w"] = float(np.nanmedian(pw))
         return out
@@ -207,28 +216,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    sampler = ClockSampler(local_rank).start() if rank == 0 else None
+    barrier()
+    t_load = time.perf_counter()
     sim.step(args.warmup)
     barrier()
     if bh:
         # The reference's disc is unbound (velocity factor 0.3): within ~10 steps most bodies have left the fixed
         # root box and the walk shrinks (SURVEY.md §6.2, §8d "time steps 1-5 only").  Warm-up therefore runs on the
         # same context (graph captured, clocks up) and the INITIAL state is uploaded again before the timed steps.
-        sim.upload(*bodies)
+        sim.upload_state(*bodies[1:5])
         barrier()
     # naive: per-kernel hipEvent timing stays on inside the timed region (2 launches per step, ~180 ms each).
     # Barnes-Hut: the timed region runs the captured hipGraph (no event pairs inside a capture); the per-kernel
     # figures come from one eager step (step 1 of the same state) AFTER it.
     sim.sim.profile(not bh).profile_reset()
-    sampler = ClockSampler(local_rank).start() if rank == 0 else None
     barrier()
     t0 = time.perf_counter()
     sim.step(args.steps)
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    clock = sampler.stop(t0, t1) if sampler else None
+    clock = sampler.stop(t_load, t1) if sampler else None
     if bh:
-        sim.upload(*bodies)
+        sim.upload_state(*bodies[1:5])
         sim.sim.profile(True).profile_reset()
         sim.step(1)                    # per-kernel times and the visit counters both describe step 1
         barrier()

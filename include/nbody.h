@@ -42,7 +42,12 @@ typedef struct nbody_config {
     float   mass;            /* mass: informational (per-body masses come from nbody_upload)      */
     float   dt;              /* dt                                                               */
     float   theta;           /* theta                                                            */
-    int32_t use_barnes_hut;  /* useBarnesHut: 0 = naive O(N^2) (benchmark.cpp:405), 1 = BH (:354)  */
+    int32_t use_barnes_hut;  /* useBarnesHut: 0 = naive O(N^2) (benchmark.cpp:405), 1 = BH (:354).  BH limits: num_bodies
+                                <= 2^28 - 64 (32-bit node indices; NBODY_ERR_INVALID beyond).  The walk masks a target's
+                                own leaf by comparing INTEGER body indices; the reference compares them as floats
+                                (benchmark.cpp:197-198, 233-235), which is the same thing up to index 2^24 (every BASELINE
+                                configuration) and beyond that also masks the odd-indexed neighbour that rounds to the
+                                same float — a reference artefact that is not reproduced                           */
     int32_t use_parallel;    /* useParallel: in the BH branch 0 means "build tree, do nothing"
                                 (benchmark.cpp:359); ignored by the naive branch, as in the reference */
     int32_t ref_compat;      /* 1: reproduce benchmark.cpp's quirks — bodies with index >= N-N%8 are never targets
@@ -92,6 +97,10 @@ int nbody_set_stream(nbody_ctx *ctx, void *hip_stream);
 int nbody_upload(nbody_ctx *ctx, const float *m, const float *posX, const float *posY,
                  const float *velX, const float *velY, const float *radius);
 
+/* New positions and velocities for the bodies of the last nbody_upload (same m and radius): skips the host-side scan
+   of the m/radius arrays, the variant choice and the rebuild of the per-body clamp constants.  Synchronous. */
+int nbody_upload_state(nbody_ctx *ctx, const float *posX, const float *posY, const float *velX, const float *velY);
+
 /* Enqueue nsteps iterations of the block benchmark.cpp:354-511 (force + forward Euler).  Returns
    once enqueued.  In a sharded context only the owned i-range is advanced; the caller all-gathers the
    position arrays (nbody_device_ptr) between steps, so nsteps must be 1 there. */
@@ -117,6 +126,10 @@ int nbody_download(nbody_ctx *ctx, float *posX, float *posY, float *velX, float 
 int nbody_comm_unique_id(char out[NBODY_COMM_ID_BYTES]);
 int nbody_comm_init(nbody_ctx *ctx, int32_t rank, int32_t nranks, const char id[NBODY_COMM_ID_BYTES]);
 int nbody_exchange_positions(nbody_ctx *ctx);
+/* The plan nbody_exchange_positions follows, as pure host arithmetic (no GPU, no RCCL): every rank's span
+   (nbody_shard_range) and whether the spans are equal and tile the array, i.e. ONE in-place ncclAllGather per
+   array (1) or one ncclBroadcast per owner (0, ragged num_bodies).  begins/counts: nranks entries each. */
+int nbody_comm_plan(int32_t num_bodies, int32_t nranks, int32_t *begins, int32_t *counts, int32_t *in_place_allgather);
 
 /* Position streaming for a viewer (the consumer is the per-frame draw loop main.cpp:646-655,
    which reads posX/posY only).  nbody_frame_publish enqueues, behind the steps enqueued so far, a device-side

@@ -21,8 +21,8 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 # every symbol include/nbody.h declares
 ABI_SYMBOLS = (
     "nbody_default_config", "nbody_shard_range", "nbody_create", "nbody_destroy", "nbody_set_stream",
-    "nbody_upload", "nbody_step", "nbody_compute_accel", "nbody_sync", "nbody_download", "nbody_frame_publish",
-    "nbody_frame_acquire", "nbody_comm_unique_id", "nbody_comm_init", "nbody_exchange_positions", "nbody_get_accel",
+    "nbody_upload", "nbody_upload_state", "nbody_step", "nbody_compute_accel", "nbody_sync", "nbody_download", "nbody_frame_publish",
+    "nbody_frame_acquire", "nbody_comm_unique_id", "nbody_comm_init", "nbody_exchange_positions", "nbody_comm_plan", "nbody_get_accel",
     "nbody_diagnostics", "nbody_device_ptr", "nbody_profile_enable", "nbody_profile_read",
     "nbody_profile_reset", "nbody_profile_samples", "nbody_get_info", "nbody_bh_tree_nodes", "nbody_bh_counters",
     "nbody_bh_group_counters", "nbody_accel_noalloc",
@@ -64,6 +64,7 @@ def lib():
         L.nbody_destroy.restype = None
         L.nbody_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.nbody_upload.argtypes = [C.c_void_p] + [_f32p] * 6
+        L.nbody_upload_state.argtypes = [C.c_void_p] + [_f32p] * 4
         L.nbody_step.argtypes = [C.c_void_p, C.c_int32]
         L.nbody_compute_accel.argtypes = [C.c_void_p]
         L.nbody_sync.argtypes = [C.c_void_p]
@@ -73,6 +74,7 @@ def lib():
         L.nbody_comm_unique_id.argtypes = [C.c_char_p]
         L.nbody_comm_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]
         L.nbody_exchange_positions.argtypes = [C.c_void_p]
+        L.nbody_comm_plan.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.nbody_get_accel.argtypes = [C.c_void_p, _f32p, _f32p]
         L.nbody_diagnostics.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.nbody_device_ptr.argtypes = [C.c_void_p, C.c_int32]
@@ -110,6 +112,13 @@ def shard_range(num_bodies, nranks, rank):
     b, c = C.c_int32(), C.c_int32()
     _check(lib().nbody_shard_range(num_bodies, nranks, rank, C.byref(b), C.byref(c)))
     return b.value, c.value
+
+
+def comm_plan(num_bodies, nranks):
+    """(spans, in_place_allgather) of the native exchange (nbody_comm_plan; host arithmetic only)."""
+    b, c, eq = (C.c_int32 * nranks)(), (C.c_int32 * nranks)(), C.c_int32()
+    _check(lib().nbody_comm_plan(num_bodies, nranks, b, c, C.byref(eq)))
+    return [(b[r], c[r]) for r in range(nranks)], bool(eq.value)
 
 
 def comm_unique_id():
@@ -173,6 +182,12 @@ class NBodySim:
         arrs = [_as_f32(a, self.n, k) for a, k in zip((m, posX, posY, velX, velY, radius),
                                                       ("m", "posX", "posY", "velX", "velY", "radius"))]
         _check(lib().nbody_upload(self._h, *[_ptr(a) for a in arrs]))
+        return self
+
+    def upload_state(self, posX, posY, velX, velY):
+        """New positions/velocities for the bodies already uploaded (nbody_upload_state)."""
+        arrs = [_as_f32(a, self.n, k) for a, k in zip((posX, posY, velX, velY), ("posX", "posY", "velX", "velY"))]
+        _check(lib().nbody_upload_state(self._h, *[_ptr(a) for a in arrs]))
         return self
 
     def download(self):

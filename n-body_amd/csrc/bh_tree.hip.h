@@ -28,12 +28,12 @@
 // Bodies EXACTLY on a split line: the reference's bounds are inclusive on all four sides
 // (benchmark.cpp:83-85), so such a body is inserted into BOTH children of an internal cell and its mass is
 // counted twice from there up (97 bodies in 10^6 — root mass 1.0001e9).  Reproduced:
-// after the first sort, bh_ties_kernel finds every body whose first x- (or y-) tie lies at a depth that is
-// internal in the tree (depth < its leaf depth, known from the neighbours' common prefixes) and emits a second
-// instance with the upper-child path; the few instances are sorted and merged into the key array before the
-// cells are counted.  Not reproduced (second order, ~1e-8 of bodies): ties that only become internal because
-// of another tie instance.  Coincident bodies stop splitting at depth 31 (the reference recurses until its
-// 32N pool is exhausted, benchmark.cpp:102).
+// bh_ties_kernel expands, for every body, the instances its split-line ties spawn against the primaries' tree, and
+// bh_tie_fixpoint_kernel closes the set (an instance can turn the leaf it lands in into an internal cell and so switch
+// on a tie of the body that lived there: a least fixed point, reproduced in full — see the comment above BhTies); the
+// instances are sorted and merged into the key array before the cells are counted.  Bodies closer together than the
+// finest cell of the 31-level key (and coincident ones) share one leaf: the reference keeps splitting them until its
+// 32N pool is exhausted (benchmark.cpp:102).
 //
 // Walk: one group of 8 consecutive body indices per 8 lanes (8 groups per wave64), the reference's vote
 // ("accept iff leaf or all 8 lanes far", benchmark.cpp:264-266) taken with one wave ballot, DFS order equal
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* __re
                                                             const int* __restrict__ owner, int n,
                                                             const float* __restrict__ m, const float* __restrict__ px,
                                                             const float* __restrict__ py, BhTree t,
-                                                            BhCounters* __restrict__ ctr)
+                                                            BhCounters* __restrict__ ctr, int* __restrict__ overflow_host)
 {
     const int c = blockIdx.x * kBhBlock + threadIdx.x;
     const int M = ctr->valid;
@@ -446,6 +446,9 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* __re
     if (c == 0) {
         ctr->internal = I < t.cap_internal ? I : t.cap_internal;
         if (I > t.cap_internal) ctr->overflow = 1;
+        // the build's verdict goes to a host-mapped word, so that nbody_sync needs no device-to-host copy (the tie
+        // buffer's overflow, 2, was set by the kernels before this one)
+        *overflow_host = I > t.cap_internal ? 1 : ctr->overflow;
         if (M < 2) {                                           // degenerate trees: root is a leaf / empty
             const int b = M == 1 ? vals[0] : -1;
             t.A[0] = make_float4(b >= 0 ? px[b] : 0.0f, b >= 0 ? py[b] : 0.0f, b >= 0 ? m[b] : 0.0f, 2.0f * spread);

@@ -64,9 +64,11 @@ int rccl_fail(const char* what, ncclResult_t r)
 
 int rccl_require()
 {
-    if (!rccl_api().ok())
+    if (!rccl_api().ok()) {
+        const char* why = dlerror();        // once: dlerror() clears the message it returns
         return fail(NBODY_ERR_UNSUPPORTED, "RCCL could not be loaded (librccl.so; set NBODY_RCCL_LIB to its path): %s",
-                    dlerror() ? dlerror() : "symbols missing");
+                    why ? why : "symbols missing");
+    }
     return NBODY_OK;
 }
 
@@ -85,6 +87,19 @@ int nbody_comm_unique_id(char out[NBODY_COMM_ID_BYTES])
     return NBODY_OK;
 }
 
+int nbody_comm_plan(int32_t num_bodies, int32_t nranks, int32_t* begins, int32_t* counts, int32_t* in_place_allgather)
+{
+    if (nranks < 1 || !begins || !counts) return fail(NBODY_ERR_INVALID, "nbody_comm_plan: bad arguments");
+    bool equal = true;
+    for (int r = 0; r < nranks; ++r) {
+        if (int rc = nbody_shard_range(num_bodies, nranks, r, &begins[r], &counts[r])) return rc;
+        equal = equal && counts[r] == counts[0];
+    }
+    equal = equal && (int64_t)counts[0] * nranks == num_bodies;
+    if (in_place_allgather) *in_place_allgather = equal ? 1 : 0;
+    return NBODY_OK;
+}
+
 int nbody_comm_init(nbody_ctx* ctx, int32_t rank, int32_t nranks, const char id[NBODY_COMM_ID_BYTES])
 {
     if (!ctx || !id) return fail(NBODY_ERR_INVALID, "nbody_comm_init: null argument");
@@ -92,10 +107,12 @@ int nbody_comm_init(nbody_ctx* ctx, int32_t rank, int32_t nranks, const char id[
     if (ctx->comm) return fail(NBODY_ERR_INVALID, "nbody_comm_init: the context already has a communicator");
     // the exchange is defined on the shard plan of nbody_shard_range: this context must own exactly its rank's share
     ctx->comm_spans.assign((size_t)nranks, {0, 0});
-    for (int r = 0; r < nranks; ++r) {
-        int32_t b = 0, c = 0;
-        if (int rc = nbody_shard_range(ctx->cfg.num_bodies, nranks, r, &b, &c)) return rc;
-        ctx->comm_spans[(size_t)r] = {b, c};
+    {
+        std::vector<int32_t> b((size_t)nranks), c((size_t)nranks);
+        int32_t eq = 0;
+        if (int rc = nbody_comm_plan(ctx->cfg.num_bodies, nranks, b.data(), c.data(), &eq)) return rc;
+        for (int r = 0; r < nranks; ++r) ctx->comm_spans[(size_t)r] = {b[(size_t)r], c[(size_t)r]};
+        ctx->comm_equal = eq != 0;
     }
     const int my_b = ctx->cfg.shard_begin;
     const int my_c = ctx->cfg.shard_count == 0 ? ctx->cfg.num_bodies - my_b : ctx->cfg.shard_count;
@@ -123,25 +140,31 @@ int nbody_exchange_positions(nbody_ctx* ctx)
     RcclApi& api = rccl_api();
     ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
     const auto& sp = ctx->comm_spans;
-    bool equal = true;
-    for (const auto& s : sp) equal = equal && s.second == sp[0].second;
-    equal = equal && (int64_t)sp[0].second * ctx->comm_nranks == ctx->cfg.num_bodies;
+    const bool equal = ctx->comm_equal;                   // nbody_comm_plan: equal shards that tile the array
     float* arrays[2] = {ctx->px, ctx->py};
     RCCL_TRY(api.GroupStart());
+    // Inside the group bracket nothing returns early: a failed call is remembered, the bracket is ALWAYS closed (an
+    // open group would silently defer every later collective of this thread), and the first failure is reported.
+    ncclResult_t first = ncclSuccess;
+    const char* what = "";
     for (float* a : arrays) {
         if (equal) {
             // in place: the send buffer is this rank's slot of the receive buffer
             const size_t cnt = (size_t)sp[0].second;
-            RCCL_TRY(api.AllGather(a + (size_t)ctx->comm_rank * cnt, a, cnt, ncclFloat, comm, ctx->stream));
+            const ncclResult_t r = api.AllGather(a + (size_t)ctx->comm_rank * cnt, a, cnt, ncclFloat, comm, ctx->stream);
+            if (r != ncclSuccess && first == ncclSuccess) { first = r; what = "ncclAllGather"; }
         } else {
-            for (int r = 0; r < ctx->comm_nranks; ++r) {      // ragged shards: one broadcast per owner
-                if (sp[(size_t)r].second == 0) continue;
-                float* p = a + sp[(size_t)r].first;
-                RCCL_TRY(api.Broadcast(p, p, (size_t)sp[(size_t)r].second, ncclFloat, r, comm, ctx->stream));
+            for (int k = 0; k < ctx->comm_nranks; ++k) {      // ragged shards: one broadcast per owner
+                if (sp[(size_t)k].second == 0) continue;
+                float* p = a + sp[(size_t)k].first;
+                const ncclResult_t r = api.Broadcast(p, p, (size_t)sp[(size_t)k].second, ncclFloat, k, comm, ctx->stream);
+                if (r != ncclSuccess && first == ncclSuccess) { first = r; what = "ncclBroadcast"; }
             }
         }
     }
-    RCCL_TRY(api.GroupEnd());
+    const ncclResult_t end = api.GroupEnd();
+    if (first != ncclSuccess) return rccl_fail(what, first);
+    if (end != ncclSuccess) return rccl_fail("ncclGroupEnd", end);
     return NBODY_OK;
 }
 

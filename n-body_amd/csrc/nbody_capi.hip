@@ -81,6 +81,7 @@ struct nbody_ctx {
     // native exchange (comm_rccl.hip.h): an ncclComm_t, kept as void* so that this struct needs no RCCL header
     void* comm = nullptr;
     int comm_rank = 0, comm_nranks = 1;
+    bool comm_equal = false;                        // in-place ncclAllGather (else one ncclBroadcast per owner)
     std::vector<std::pair<int, int>> comm_spans;   // (begin, count) of every rank
     // position streaming (nbody_frame_*): device snapshots + pinned host frames, copied on their own stream
     struct Frames {
@@ -112,6 +113,7 @@ struct nbody_ctx {
         size_t gsort_bytes = 0;
         BhTree tree{};
         BhCounters* ctr = nullptr;
+        int *overflow_host = nullptr, *overflow_dev = nullptr;   // pinned, device-mapped word: the last build's overflow flag
         int *grp_visits = nullptr, *grp_accepts = nullptr;   // per group of 8 bodies, written by every walk
         void *sort_tmp = nullptr, *scan_tmp = nullptr;
         size_t sort_bytes = 0, scan_bytes = 0;
@@ -262,7 +264,7 @@ int enqueue_bh_build(nbody_ctx* ctx)
     const dim3 grid_c((b.tree.cap_internal + kBhBlock - 1) / kBhBlock);
     bh_owner_kernel<<<grid_m, blk, 0, s>>>(b.cnt, b.base, nm, b.ctr, b.owner, b.tree.cap_internal);
     bh_nodes_kernel<<<grid_c, blk, 0, s>>>(b.keys_merged, b.vals_merged, b.cnt, b.base, b.owner, nm, ctx->m, ctx->px, ctx->py,
-                                           b.tree, b.ctr);
+                                           b.tree, b.ctr, b.overflow_dev);
     // centre of mass: ONE single-workgroup launch covers trees of <= kComSmall internal cells (the cell count is
     // only known on the device, so the kernels decide there which of the two paths runs); per-depth launches
     // otherwise.  Contexts whose pool cannot exceed kComSmall cells never enqueue the per-depth launches.
@@ -399,6 +401,11 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
         return fail(NBODY_ERR_INVALID, "nbody_create: force_variant=%d", cfg->force_variant);
     if (cfg->use_barnes_hut && !cfg->adaptive_box && !(cfg->spread > 0.0f))
         return fail(NBODY_ERR_INVALID, "nbody_create: Barnes-Hut needs spread > 0 (root box), got %g", cfg->spread);
+    // Barnes-Hut indices are 32-bit: node index <= 4 * (2 n + 64) must fit in int32 (the pool still fits 288 GB of HBM
+    // around n = 2^28, so without this bound an overflow would be an out-of-bounds write, not an allocation failure)
+    constexpr int kBhMaxBodies = (1 << 28) - 64;
+    if (cfg->use_barnes_hut && n > kBhMaxBodies)
+        return fail(NBODY_ERR_INVALID, "nbody_create: Barnes-Hut supports at most %d bodies (32-bit node indices), got %d", kBhMaxBodies, n);
     if (cfg->use_barnes_hut && cfg->shard_begin % 8 != 0)
         return fail(NBODY_ERR_INVALID, "nbody_create: Barnes-Hut shards must start on a multiple of 8 (groups of 8 bodies)");
     int ndev = 0;
@@ -477,6 +484,9 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
         HIP_TRY_C(hipMalloc((void**)&b.tree.self, sizeof(int) * (size_t)b.tree.cap_internal));
         HIP_TRY_C(hipMalloc((void**)&b.ctr, sizeof(BhCounters)));
         HIP_TRY_C(hipMemset(b.ctr, 0, sizeof(BhCounters)));
+        HIP_TRY_C(hipHostMalloc((void**)&b.overflow_host, sizeof(int), hipHostMallocMapped));
+        *b.overflow_host = 0;
+        HIP_TRY_C(hipHostGetDevicePointer((void**)&b.overflow_dev, b.overflow_host, 0));
         HIP_TRY_C(hipMalloc((void**)&b.grp_visits, sizeof(int) * ((size_t)n / 8 + 1)));
         HIP_TRY_C(hipMalloc((void**)&b.grp_accepts, sizeof(int) * ((size_t)n / 8 + 1)));
         HIP_TRY_C(hipMemset(b.grp_visits, 0, sizeof(int) * ((size_t)n / 8 + 1)));
@@ -511,6 +521,7 @@ void nbody_destroy(nbody_ctx* ctx)
                         b.gvals_sorted, b.keys_merged, b.vals_merged, b.gsort_tmp, b.grp_visits, b.grp_accepts};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
+        if (b.overflow_host) (void)hipHostFree(b.overflow_host);
     }
     for (auto& pool : ctx->prof.pool)
         for (auto& ep : pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -607,6 +618,31 @@ int nbody_upload(nbody_ctx* ctx, const float* m, const float* posX, const float*
     ctx->uploaded = true;
     ctx->steps_enqueued = 0;
     if (ctx->frames.ready) {                     // frames of the previous state are dropped
+        HIP_TRY(hipStreamSynchronize(ctx->frames.copy_stream));
+        ctx->frames.acquired = ctx->frames.published;
+    }
+    return NBODY_OK;
+}
+
+int nbody_upload_state(nbody_ctx* ctx, const float* posX, const float* posY, const float* velX, const float* velY)
+{
+    if (!ctx || !posX || !posY || !velX || !velY) return fail(NBODY_ERR_INVALID, "nbody_upload_state: null argument");
+    if (!ctx->uploaded) return fail(NBODY_ERR_INVALID, "nbody_upload_state: call nbody_upload first (it brings m and radius)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int n = ctx->cfg.num_bodies;
+    bool finite = true;
+    for (int i = 0; i < n; ++i) finite &= std::isfinite(posX[i]) && std::isfinite(posY[i]);
+    if (!finite) return fail(NBODY_ERR_INVALID, "nbody_upload_state: non-finite position");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const size_t nb = sizeof(float) * (size_t)n;
+    HIP_TRY(hipMemcpy(ctx->px, posX, nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->py, posY, nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->vx, velX, nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->vy, velY, nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(ctx->ax, 0, nb));
+    HIP_TRY(hipMemset(ctx->ay, 0, nb));
+    ctx->steps_enqueued = 0;
+    if (ctx->frames.ready) {
         HIP_TRY(hipStreamSynchronize(ctx->frames.copy_stream));
         ctx->frames.acquired = ctx->frames.published;
     }
@@ -723,12 +759,13 @@ int nbody_sync(nbody_ctx* ctx)
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->cfg.use_barnes_hut) {
-        BhCounters h{};
-        HIP_TRY(hipMemcpy(&h, ctx->bh.ctr, sizeof(h), hipMemcpyDeviceToHost));
-        if (h.overflow == 1)
+        // the flag of the LAST build, written by its node kernel into host-mapped memory: no copy, no extra sync
+        // (the C++ loops call nbody_sync every frame of a ~0.3 ms step)
+        const int overflow = *static_cast<volatile int*>(ctx->bh.overflow_host);
+        if (overflow == 1)
             return fail(NBODY_ERR_INVALID, "Barnes-Hut node pool exhausted (%d internal cells); bodies were dropped from the tree "
                                            "as the reference does at benchmark.cpp:102", ctx->bh.tree.cap_internal);
-        if (h.overflow == 2)
+        if (overflow == 2)
             return fail(NBODY_ERR_INVALID, "Barnes-Hut: more than %d bodies sit exactly on split lines; the surplus was inserted once",
                         ctx->bh.gcap);
     }

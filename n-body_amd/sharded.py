@@ -89,6 +89,11 @@ class ShardedSim:
         self.prepare_exchange()
         return self
 
+    def upload_state(self, posX, posY, velX, velY):
+        """Back to another state of the same bodies (bench.py re-uploads the initial state after the warm-up)."""
+        self.sim.upload_state(posX, posY, velX, velY)
+        return self
+
     def prepare_exchange(self, force=False):
         """Staging buffers, once per upload (force: also with one rank — tools/dist_probe.py)."""
         t = self.torch

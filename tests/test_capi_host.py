@@ -52,6 +52,41 @@ def test_shard_range_rejects_bad_arguments(nb):
         nb.shard_range(100, 4, 4)
 
 
+@pytest.mark.parametrize("n,p", [(1 << 20, 8), (10000, 8), (1003, 4), (65536, 3), (17, 8), (4096, 2), (5, 2)])
+def test_native_exchange_plan_equals_the_torch_drivers(nb, n, p):
+    """The native exchange (nbody_exchange_positions / `nbody_benchmark --dist`: one in-place ncclAllGather per array,
+    or one ncclBroadcast per owner when the shards are ragged, comm_rccl.hip.h) follows nbody_comm_plan; the torch
+    driver (sharded.exchange_slices) decides the same way from the same spans.  Both plans, played on numpy arrays,
+    rebuild the full array from the ranks' owned slices."""
+    spans, in_place = nb.comm_plan(n, p)
+    assert spans == [nb.shard_range(n, p, r) for r in range(p)]
+    counts = {c for _, c in spans}
+    assert in_place == (len(counts) == 1 and spans[0][1] * p == n)        # exchange_slices' own condition
+    truth = np.arange(n, dtype=np.float32)
+    ranks = []
+    for r, (b, c) in enumerate(spans):                                     # every rank holds only its slice
+        a = np.full(n, -1.0, np.float32)
+        a[b:b + c] = truth[b:b + c]
+        ranks.append(a)
+    if in_place:
+        cnt = spans[0][1]
+        gathered = np.concatenate([ranks[r][r * cnt:(r + 1) * cnt] for r in range(p)])   # ncclAllGather, rank order
+        for a in ranks:
+            a[:] = gathered
+    else:
+        for owner, (b, c) in enumerate(spans):                             # ncclBroadcast(root = owner) of its span
+            for a in ranks:
+                a[b:b + c] = ranks[owner][b:b + c]
+    for a in ranks:
+        assert np.array_equal(a, truth)
+
+
+def test_barnes_hut_rejects_sizes_beyond_32_bit_node_indices(nb):
+    with pytest.raises(nb.NBodyError) as e:
+        nb.NBodySim((1 << 28), useBarnesHut=True)
+    assert e.value.code == nb.ERR_INVALID and "32-bit" in str(e.value)
+
+
 def _have_gpu():
     try:
         import torch

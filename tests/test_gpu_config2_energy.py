@@ -4,8 +4,11 @@ The CPU side is the compiled reference itself (oracle/_ref, benchmark.cpp's own 
 box, advanced in 4 legs of 25 steps from the same seeded disc; energies of both trajectories are evaluated by the
 f64-accumulating GPU diagnostics kernel (itself checked against the oracle in test_gpu_naive.py).  The system is
 chaotic and forward Euler at dt = 0.05 with mass 1000 per body is violent: trajectories are NOT
-compared, the conserved-quantity drift curves are.  Stated bound: |drift_gpu - drift_cpu| <= 2 % of |E0| at every
-checkpoint; momentum change <= 1e-4 of sum m|v| on both."""
+compared, the conserved-quantity drift curves are.  Measured (round 2, profiles/r2_config2_energy_drift.txt): the
+energy itself changes by +115 % of |E0| within 25 steps (the disc is unbound and forward Euler heats it), and the GPU
+and reference curves differ by 3.6e-5, 1.8e-5, 9e-6, 5e-6 of |E0| at steps 25/50/75/100.  Stated bound: ten times the
+largest observed difference, |drift_gpu - drift_cpu| <= 4e-4 of |E0| at every checkpoint; momentum change <= 1e-4 of
+sum m|v| on both."""
 import numpy as np
 import pytest
 
@@ -42,8 +45,9 @@ def test_config2_energy_and_momentum_drift(nb, O):
     assert e_gpu[0] == e_cpu[0]
     drift_gpu = (e_gpu - e_gpu[0]) / abs(e_gpu[0])
     drift_cpu = (e_cpu - e_cpu[0]) / abs(e_cpu[0])
-    print("energy drift gpu", drift_gpu, "cpu(reference)", drift_cpu)
-    assert np.all(np.abs(drift_gpu - drift_cpu) <= 0.02), (drift_gpu, drift_cpu)
     scale = np.sum(b.m.astype(np.float64) * np.hypot(b.velX, b.velY))
-    for p in (p_gpu, p_cpu):
-        assert max(np.linalg.norm(q - p[0]) for q in p) <= 1e-4 * scale
+    mom = [[float(np.linalg.norm(q - p[0]) / scale) for q in p] for p in (p_gpu, p_cpu)]
+    print("energy drift gpu", drift_gpu, "cpu(reference)", drift_cpu, "difference", drift_gpu - drift_cpu)
+    print("momentum change / sum m|v|: gpu", mom[0], "cpu(reference)", mom[1])
+    assert np.all(np.abs(drift_gpu - drift_cpu) <= 4e-4), (drift_gpu, drift_cpu)
+    assert max(mom[0]) <= 1e-4 and max(mom[1]) <= 1e-4
