@@ -130,7 +130,7 @@ def test_tree_identical_to_reference(O):
     assert st["bodies"] >= b.n        # >= : a body exactly on a split line enters 2+ children
 
 
-@pytest.mark.parametrize("name", ["bh_n1003_theta1", "bh_n10000_theta1", "bh_n10000_theta05"])
+@pytest.mark.parametrize("name", ["bh_n1003_theta1", "bh_n10000_theta1", "bh_n10000_theta05", "bh_close_pair_n512"])
 def test_tree_node_count(O, name):
     g, b = load_golden(O, name)
     t = O.Tree(b.n).build(b, float(g["spread"]))
@@ -155,7 +155,7 @@ def test_bh_accel_vs_reference(O, name):
     assert cnt["accepts"] > 0 and cnt["visits"] >= cnt["accepts"]
 
 
-BH_GOLDEN = ["bh_n1024_theta1", "bh_n1003_theta1", "bh_n10000_theta1", "bh_n10000_theta05"]
+BH_GOLDEN = ["bh_n1024_theta1", "bh_n1003_theta1", "bh_n10000_theta1", "bh_n10000_theta05", "bh_close_pair_n512"]
 
 
 @pytest.mark.parametrize("name", BH_GOLDEN)
