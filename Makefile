@@ -15,6 +15,11 @@ $(LIB): $(CSRC)/nbody_capi.hip $(KERNEL_HDRS)
 	@mkdir -p $(PKG)/lib
 	$(HIPCC) $(HIPFLAGS) -shared $< -o $@ -ldl
 
+# developer build: bh_walk_wide_kernel returns per-phase ticks (tools/wide_timing.py)
+lib-timing: $(CSRC)/nbody_capi.hip $(KERNEL_HDRS)
+	@mkdir -p $(PKG)/lib
+	$(HIPCC) $(HIPFLAGS) -DNBODY_WIDE_TIMING -shared $< -o $(PKG)/lib/libnbody_amd_timing.so -ldl
+
 # C++ host drivers: counterparts of the reference's benchmark.cpp / main.cpp loops, calling the C-ABI.
 host: $(PKG)/bin/nbody_benchmark $(PKG)/bin/nbody_sim
 
@@ -41,4 +46,4 @@ clean:
 	rm -rf $(PKG)/lib $(PKG)/bin tools/ubench tools/kbench2
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib host oracle tools clean
+.PHONY: all lib lib-timing host oracle tools clean

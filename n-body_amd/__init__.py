@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnbody_amd.so")
+LIB_PATH = os.environ.get("NBODY_AMD_LIB") or os.path.join(_HERE, "lib", "libnbody_amd.so")   # env: developer builds
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 

@@ -45,6 +45,16 @@
 
 namespace nbody {
 
+#ifdef NBODY_WIDE_TIMING
+#define BH_DBG_TICK(ctr, k) do { if (threadIdx.x == 0) (ctr)->dbg[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BH_DBG_TICK(ctr, k) do { } while (0)
+#endif
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load and store the
+// wave has in flight (its fence covers all address spaces): in a one-workgroup kernel that keeps prefetches and
+// result stores in flight across its phases, that turns every barrier into a ~2 us memory round trip.
+__device__ __forceinline__ void bh_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int kBhLevels = 31;                       // path-key digits (2 bits each)
 constexpr uint64_t kBhInvalidKey = 1ull << 63;      // outside the root box
 constexpr int kBhBlock = 256;
@@ -58,7 +68,11 @@ struct BhCounters {          // device-resident scalars of one build/walk
     unsigned long long visits, accepts;
     unsigned long long wave_iters;   // walk: loop iterations summed over waves (lane utilisation = visits / (8 * wave_iters))
     float root_half;         // half-width h of the root box [-h,h]^2 of this build (= spread unless adaptive)
-    int pad_;
+#ifdef NBODY_WIDE_TIMING
+    unsigned long long dbg[24];  // developer build: 100 MHz ticks at phase boundaries of the one-workgroup kernels
+#endif
+    int valid_acc;           // small-N build: in-box bodies counted by bh_keys_kernel (one atomic per wave); moved into
+                             // `valid` and zeroed by bh_prep_small_kernel
 };
 
 // walk record of a node: A = {comX, comY, mass, width}, B = {childBase (-1: leaf), bodyIndex (-1: none)}
@@ -89,36 +103,46 @@ __global__ __launch_bounds__(kBhBlock) void bh_keys_kernel(const float* __restri
                                                            int fixed_box, uint64_t* __restrict__ keys,
                                                            int* __restrict__ vals, uint16_t* __restrict__ tie,
                                                            uint64_t* __restrict__ gkeys, int* __restrict__ gvals, int gcap,
-                                                           int* __restrict__ tie_table, int tie_table_size)
+                                                           int* __restrict__ tie_table, int tie_table_size, int count_valid)
 {
     const int i = blockIdx.x * kBhBlock + threadIdx.x;
     for (int g = i; g < gcap; g += gridDim.x * kBhBlock) { gkeys[g] = ~0ull; gvals[g] = -1; }
     for (int g = i; g < tie_table_size; g += gridDim.x * kBhBlock) tie_table[g] = -1;
     if (fixed_box && i == 0) bh_reset_counters(ctr, spread_fixed);
-    if (i >= n) return;
-    const float spread = fixed_box ? spread_fixed : ctr->root_half;
-    const float x = px[i], y = py[i];
-    float tlx = -spread, tly = -spread, brx = spread, bry = spread;
-    uint64_t key;
-    int tx = kBhLevels, ty = kBhLevels;                    // first level at which x (y) sits ON the split line
-    if (x < tlx || x > brx || y < tly || y > bry) {         // benchmark.cpp:83-85
-        key = kBhInvalidKey | (uint64_t)(uint32_t)i;       // keep invalid keys distinct and ordered
-    } else {
-        key = 0;
+    bool inside = false;
+    if (i < n) {
+        const float spread = fixed_box ? spread_fixed : ctr->root_half;
+        const float x = px[i], y = py[i];
+        float tlx = -spread, tly = -spread, brx = spread, bry = spread;
+        uint64_t key;
+        int tx = kBhLevels, ty = kBhLevels;                    // first level at which x (y) sits ON the split line
+        if (x < tlx || x > brx || y < tly || y > bry) {         // benchmark.cpp:83-85
+            key = kBhInvalidKey | (uint64_t)(uint32_t)i;       // keep invalid keys distinct and ordered
+        } else {
+            inside = true;
+            key = 0;
 #pragma unroll 1
-        for (int l = 0; l < kBhLevels; ++l) {
-            const float mx = (tlx + brx) / 2.0f, my = (tly + bry) / 2.0f;    // benchmark.cpp:98-99
-            tx = (x == mx && tx == kBhLevels) ? l : tx;
-            ty = (y == my && ty == kBhLevels) ? l : ty;
-            const int qx = x > mx, qy = y > my;            // on the line -> lower child
-            key = (key << 2) | (uint64_t)(qy * 2 + qx);    // TL, TR, BL, BR (benchmark.cpp:105-108)
-            tlx = qx ? mx : tlx; brx = qx ? brx : mx;
-            tly = qy ? my : tly; bry = qy ? bry : my;
+            for (int l = 0; l < kBhLevels; ++l) {
+                const float mx = (tlx + brx) / 2.0f, my = (tly + bry) / 2.0f;    // benchmark.cpp:98-99
+                tx = (x == mx && tx == kBhLevels) ? l : tx;
+                ty = (y == my && ty == kBhLevels) ? l : ty;
+                const int qx = x > mx, qy = y > my;            // on the line -> lower child
+                key = (key << 2) | (uint64_t)(qy * 2 + qx);    // TL, TR, BL, BR (benchmark.cpp:105-108)
+                tlx = qx ? mx : tlx; brx = qx ? brx : mx;
+                tly = qy ? my : tly; bry = qy ? bry : my;
+            }
         }
+        keys[i] = key;
+        vals[i] = i;
+        tie[i] = (uint16_t)(tx | (ty << 8));
     }
-    keys[i] = key;
-    vals[i] = i;
-    tie[i] = (uint16_t)(tx | (ty << 8));
+    // small-N build (count_valid): number of in-box bodies = where the invalid keys start after the sort; one atomic
+    // per wave (a few hundred in all — at 10^6 bodies the 15 625 same-address atomics would cost more than the
+    // binary search of bh_valid_kernel, which the large build keeps)
+    if (count_valid) {
+        const unsigned long long in_mask = __ballot(inside);
+        if ((threadIdx.x & 63) == 0 && in_mask) atomicAdd(&ctr->valid_acc, __popcll(in_mask));
+    }
 }
 
 // number of valid (in-box) bodies = first sorted index with the invalid bit set
@@ -277,14 +301,10 @@ __device__ __forceinline__ int bh_first_tie(uint16_t rec)
     return tx < ty ? tx : ty;                                    // kBhLevels when the primary's path has none
 }
 
-__global__ __launch_bounds__(kBhBlock) void bh_ties_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
-                                                           const float* __restrict__ px, const float* __restrict__ py,
-                                                           const uint16_t* __restrict__ tie, BhCounters* __restrict__ ctr,
-                                                           BhTies T)
+__device__ __forceinline__ void bh_ties_one(int i, int M, const uint64_t* __restrict__ keys, const int* __restrict__ vals,
+                                            const float* __restrict__ px, const float* __restrict__ py,
+                                            const uint16_t* __restrict__ tie, BhCounters* __restrict__ ctr, const BhTies& T)
 {
-    const int i = blockIdx.x * kBhBlock + threadIdx.x;
-    const int M = ctr->valid;
-    if (i >= M) return;
     const int b = vals[i];
     const int first = bh_first_tie(tie[b]);
     if (first == kBhLevels) return;                              // no split line on the primary's path:
@@ -297,11 +317,22 @@ __global__ __launch_bounds__(kBhBlock) void bh_ties_kernel(const uint64_t* __res
     bh_spawn_ties(px[b], py[b], ctr->root_half, 0u, 0u, 0, leaf_depth, b, first, keys, vals, M, T, ctr);
 }
 
+__global__ __launch_bounds__(kBhBlock) void bh_ties_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
+                                                           const float* __restrict__ px, const float* __restrict__ py,
+                                                           const uint16_t* __restrict__ tie, BhCounters* __restrict__ ctr,
+                                                           BhTies T)
+{
+    const int i = blockIdx.x * kBhBlock + threadIdx.x;
+    const int M = ctr->valid;
+    if (i >= M) return;
+    bh_ties_one(i, M, keys, vals, px, py, tie, ctr, T);
+}
+
 constexpr int kBhFixBlock = 1024;
-__global__ __launch_bounds__(kBhFixBlock) void bh_tie_fixpoint_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
-                                                                      const float* __restrict__ px, const float* __restrict__ py,
-                                                                      const uint16_t* __restrict__ tie, BhCounters* __restrict__ ctr,
-                                                                      BhTies T)
+__device__ __forceinline__ void bh_tie_fixpoint_body(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
+                                                     const float* __restrict__ px, const float* __restrict__ py,
+                                                     const uint16_t* __restrict__ tie, BhCounters* __restrict__ ctr,
+                                                     const BhTies& T)
 {
     __shared__ int s_end;
     const int M = ctr->valid;
@@ -355,16 +386,19 @@ __global__ __launch_bounds__(kBhFixBlock) void bh_tie_fixpoint_kernel(const uint
     }
 }
 
-// merge sorted primaries [n] and sorted second instances [gcap] into one sorted array [n + gcap]
-__global__ __launch_bounds__(kBhBlock) void bh_merge_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals, int n,
-                                                            const uint64_t* __restrict__ gkeys, const int* __restrict__ gvals,
-                                                            int gcap, uint64_t* __restrict__ okeys, int* __restrict__ ovals,
-                                                            BhCounters* __restrict__ ctr)
+__global__ __launch_bounds__(kBhFixBlock) void bh_tie_fixpoint_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
+                                                                      const float* __restrict__ px, const float* __restrict__ py,
+                                                                      const uint16_t* __restrict__ tie, BhCounters* __restrict__ ctr,
+                                                                      BhTies T)
 {
-    const int t = blockIdx.x * kBhBlock + threadIdx.x;
-    // valid INSTANCES of the merged array = valid primaries + second instances (their keys have bit 63 clear, the
-    // padding and the out-of-box bodies have it set and sort behind them); nobody else in this launch reads ctr
-    if (t == 0) ctr->valid += ctr->ghosts < gcap ? ctr->ghosts : gcap;
+    bh_tie_fixpoint_body(keys, vals, px, py, tie, ctr, T);
+}
+
+// merge sorted primaries [n] and sorted second instances [gcap] into one sorted array [n + gcap]
+__device__ __forceinline__ void bh_merge_one(int t, const uint64_t* __restrict__ keys, const int* __restrict__ vals, int n,
+                                             const uint64_t* __restrict__ gkeys, const int* __restrict__ gvals, int gcap,
+                                             uint64_t* __restrict__ okeys, int* __restrict__ ovals)
+{
     if (t < n) {
         const uint64_t k = keys[t];
         int lo = 0, hi = gcap;                                 // second instances with a smaller key
@@ -381,21 +415,34 @@ __global__ __launch_bounds__(kBhBlock) void bh_merge_kernel(const uint64_t* __re
     }
 }
 
+__global__ __launch_bounds__(kBhBlock) void bh_merge_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals, int n,
+                                                            const uint64_t* __restrict__ gkeys, const int* __restrict__ gvals,
+                                                            int gcap, uint64_t* __restrict__ okeys, int* __restrict__ ovals,
+                                                            BhCounters* __restrict__ ctr)
+{
+    const int t = blockIdx.x * kBhBlock + threadIdx.x;
+    // valid INSTANCES of the merged array = valid primaries + second instances (their keys have bit 63 clear, the
+    // padding and the out-of-box bodies have it set and sort behind them); nobody else in this launch reads ctr
+    if (t == 0) ctr->valid += ctr->ghosts < gcap ? ctr->ghosts : gcap;
+    bh_merge_one(t, keys, vals, n, gkeys, gvals, gcap, okeys, ovals);
+}
+
 // 3. internal cells owned by each sorted body --------------------------------------------------------------
+__device__ __forceinline__ int bh_count_one(int i, int M, const uint64_t* __restrict__ keys)
+{
+    if (i >= M) return 0;
+    const uint64_t k = keys[i];
+    const int lp = i > 0 ? bh_lcp_levels(keys[i - 1], k) : -1;
+    const int ln = i + 1 < M ? bh_lcp_levels(k, keys[i + 1]) : -1;
+    return ln > lp ? ln - lp : 0;
+}
+
 __global__ __launch_bounds__(kBhBlock) void bh_count_kernel(const uint64_t* __restrict__ keys, int n,
                                                             const BhCounters* __restrict__ ctr, int* __restrict__ cnt)
 {
     const int i = blockIdx.x * kBhBlock + threadIdx.x;
     if (i >= n) return;
-    const int M = ctr->valid;
-    int c = 0;
-    if (i < M) {
-        const uint64_t k = keys[i];
-        const int lp = i > 0 ? bh_lcp_levels(keys[i - 1], k) : -1;
-        const int ln = i + 1 < M ? bh_lcp_levels(k, keys[i + 1]) : -1;
-        c = ln > lp ? ln - lp : 0;
-    }
-    cnt[i] = c;
+    cnt[i] = bh_count_one(i, ctr->valid, keys);
 }
 
 __device__ __forceinline__ int bh_lower_bound(const uint64_t* __restrict__ keys, int lo, int hi, uint64_t v)
@@ -430,15 +477,149 @@ __global__ __launch_bounds__(kBhBlock) void bh_owner_kernel(const int* __restric
         if (c0 + k < cap_internal) owner[c0 + k] = i;
 }
 
+// Small N: steps 2b-4a in ONE launch of one workgroup (valid count, split-line instances and their fixed point, their
+// sort — bitonic in LDS, nothing to do when there are none —, merge, cell counting, exclusive scan, owner scatter).
+// At N = 10 000 these were 12 launches of 4-5 us each around a few hundred nanoseconds of work (the reference's own
+// default size, benchmark.cpp:302; a captured graph replays launches no faster than the stream issues them).
+// Same device functions as the separate kernels, phases separated by workgroup barriers; results are identical.
+constexpr int kBhSmallMax = 32768;                  // bodies; above, the phases are separate full-width launches
+constexpr int kBhSmallGhosts = 4096;                // second instances the LDS sort holds (= the tie buffer below 2^20 bodies)
+
+__global__ __launch_bounds__(kBhFixBlock) void bh_prep_small_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
+                                                                    const float* __restrict__ px, const float* __restrict__ py,
+                                                                    const uint16_t* __restrict__ tie, BhCounters* __restrict__ ctr,
+                                                                    BhTies T, int n, uint64_t* __restrict__ gkeys_sorted,
+                                                                    int* __restrict__ gvals_sorted, uint64_t* __restrict__ okeys,
+                                                                    int* __restrict__ ovals, int* __restrict__ cnt,
+                                                                    int* __restrict__ base, int* __restrict__ owner, int cap_internal)
+{
+    __shared__ uint64_t sk[kBhSmallGhosts];
+    __shared__ int sv[kBhSmallGhosts];
+    __shared__ int part[kBhFixBlock / 64];
+    const int tid = threadIdx.x;
+    BH_DBG_TICK(ctr, 0);
+    const int M0 = ctr->valid_acc;                                 // counted by bh_keys_kernel; zeroed below for the next build
+    // 2b. second instances of bodies on split lines.  All but a few bodies per million have no tie on their path:
+    // the two dependent loads that say so (body of the sorted slot, its tie record) are issued eight at a time.
+    constexpr int kBatch = 16;
+    for (int i0 = tid; i0 < M0; i0 += kBatch * kBhFixBlock) {
+        int bb[kBatch], first[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) { const int i = i0 + u * kBhFixBlock; bb[u] = i < M0 ? vals[i] : -1; }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) first[u] = bb[u] >= 0 ? bh_first_tie(tie[bb[u]]) : kBhLevels;
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u)
+            if (first[u] != kBhLevels) bh_ties_one(i0 + u * kBhFixBlock, M0, keys, vals, px, py, tie, ctr, T);
+    }
+    __syncthreads();            // one workgroup = one CU = one L1: a barrier is all the ordering the phases need
+    if (tid == 0) { ctr->valid = M0; ctr->valid_acc = 0; }
+    BH_DBG_TICK(ctr, 1);
+    bh_tie_fixpoint_body(keys, vals, px, py, tie, ctr, T);
+    BH_DBG_TICK(ctr, 2);
+    const int ghosts = __hip_atomic_load(&ctr->ghosts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int gmax = T.gcap < kBhSmallGhosts ? T.gcap : kBhSmallGhosts;
+    const int G = ghosts < gmax ? ghosts : gmax;
+    const uint64_t* mk = keys;                                     // the merged arrays ARE the sorted primaries ...
+    const int* mv = vals;
+    if (G > 0) {                                                   // ... unless there are second instances (rare):
+        __syncthreads();                                           // sort them by key, bitonic, in LDS, and merge
+        int P = 2;
+        while (P < G) P <<= 1;
+        for (int e = tid; e < P; e += kBhFixBlock) { sk[e] = e < G ? T.gkeys[e] : ~0ull; sv[e] = e < G ? T.gvals[e] : -1; }
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int p = tid; p < (P >> 1); p += kBhFixBlock) {
+                    const int lo = ((p & ~(j - 1)) << 1) | (p & (j - 1)), hi = lo | j;
+                    const uint64_t ka = sk[lo], kb = sk[hi];
+                    const int va = sv[lo], vb = sv[hi];
+                    // total order (key, body): equal keys of different bodies come out the same way every time
+                    const bool gt = ka > kb || (ka == kb && va > vb);
+                    if (gt == ((lo & k) == 0)) { sk[lo] = kb; sk[hi] = ka; sv[lo] = vb; sv[hi] = va; }
+                }
+                __syncthreads();
+            }
+        for (int e = tid; e < G; e += kBhFixBlock) { gkeys_sorted[e] = sk[e]; gvals_sorted[e] = sv[e]; }
+        __syncthreads();
+        for (int t = tid; t < n + G; t += kBhFixBlock) bh_merge_one(t, keys, vals, n, gkeys_sorted, gvals_sorted, G, okeys, ovals);
+        __syncthreads();
+        mk = okeys;
+        mv = ovals;
+    }
+    (void)mv;
+    const int M = M0 + G;
+    BH_DBG_TICK(ctr, 3);
+    if (tid == 0) ctr->valid = M;
+    // 3. cells owned by each instance, their exclusive scan (= cell ids) and 4a. the owner of every cell, in rounds
+    // of 1024 consecutive instances: coalesced loads (8 rounds in flight per thread), a shuffle scan inside each
+    // wave, the 16 wave totals through LDS, coalesced stores.
+    const int lane = tid & 63, wave = tid >> 6;
+    int running = 0;                                               // cells before this round (block-uniform)
+    constexpr int kRounds = 8;                                     // 3 keys x 8 rounds in flight: 48 VGPRs
+    for (int i0 = 0; i0 < M; i0 += kRounds * kBhFixBlock) {
+        uint64_t kp[kRounds], kc[kRounds], kn[kRounds];
+#pragma unroll
+        for (int u = 0; u < kRounds; ++u) {
+            const int i = i0 + u * kBhFixBlock + tid;
+            kc[u] = i < M ? mk[i] : 0;
+            kp[u] = i < M && i > 0 ? mk[i - 1] : 0;
+            kn[u] = i + 1 < M ? mk[i + 1] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kRounds; ++u) {
+            const int r0 = i0 + u * kBhFixBlock;
+            if (r0 < M) {                                          // block-uniform
+                const int i = r0 + tid;
+                int c = 0;
+                if (i < M) {
+                    const int lp = i > 0 ? bh_lcp_levels(kp[u], kc[u]) : -1;
+                    const int ln = i + 1 < M ? bh_lcp_levels(kc[u], kn[u]) : -1;
+                    c = ln > lp ? ln - lp : 0;
+                }
+                int incl = c;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int v = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += v;
+                }
+                if (lane == 63) part[wave] = incl;
+                bh_lds_barrier();
+                int before = running, total = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < kBhFixBlock / 64; ++w2) {
+                    const int pw = part[w2];
+                    before += w2 < wave ? pw : 0;
+                    total += pw;
+                }
+                bh_lds_barrier();                                  // part[] is read before the next round rewrites it
+                running += total;
+                if (i < M) {
+                    const int first = before + incl - c;
+                    cnt[i] = c;
+                    base[i] = first;
+                    for (int k = 0; k < c; ++k)
+                        if (first + k < cap_internal) owner[first + k] = i;
+                }
+            }
+        }
+    }
+    BH_DBG_TICK(ctr, 6);
+}
+
 // 4b. one thread per internal cell: box, body range (galloping from the owner: the range of a typical cell is a
 // few bodies long), the four children.
-__global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
+__global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys, const int* vals,
                                                             const int* __restrict__ cnt, const int* __restrict__ base,
                                                             const int* __restrict__ owner, int n,
                                                             const float* __restrict__ m, const float* __restrict__ px,
                                                             const float* __restrict__ py, BhTree t,
-                                                            BhCounters* __restrict__ ctr, int* __restrict__ overflow_host)
+                                                            BhCounters* __restrict__ ctr, int* __restrict__ overflow_host,
+                                                            const uint64_t* __restrict__ keys_unmerged,
+                                                            const int* __restrict__ vals_unmerged)
 {
+    // small-N build: without second instances the merged arrays were never written, they ARE the sorted primaries
+    if (keys_unmerged != nullptr && ctr->ghosts == 0) { keys = keys_unmerged; vals = vals_unmerged; }
     const int c = blockIdx.x * kBhBlock + threadIdx.x;
     const int M = ctr->valid;
     const float spread = ctr->root_half;
@@ -448,7 +629,8 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* __re
         if (I > t.cap_internal) ctr->overflow = 1;
         // the build's verdict goes to a host-mapped word, so that nbody_sync needs no device-to-host copy (the tie
         // buffer's overflow, 2, was set by the kernels before this one)
-        *overflow_host = I > t.cap_internal ? 1 : ctr->overflow;
+        overflow_host[0] = I > t.cap_internal ? 1 : ctr->overflow;
+        overflow_host[1] = I < t.cap_internal ? I : t.cap_internal;     // hint for the NEXT build's choice of COM pass
         if (M < 2) {                                           // degenerate trees: root is a leaf / empty
             const int b = M == 1 ? vals[0] : -1;
             t.A[0] = make_float4(b >= 0 ? px[b] : 0.0f, b >= 0 ? py[b] : 0.0f, b >= 0 ? m[b] : 0.0f, 2.0f * spread);
@@ -600,25 +782,124 @@ __global__ __launch_bounds__(kBhBlock) void bh_com_kernel(BhTree t, const BhCoun
 }
 
 // Small trees: all depths in ONE launch of one workgroup (31 launches of a few microseconds each are most of a
-// Barnes-Hut step at N = 10 000).  Falls through to nothing when the tree is larger than `max_internal`.
-constexpr int kBhComBlock = 1024;
+// Barnes-Hut step at N = 10 000).
+//
+// Up to kBhComLds cells the level loop runs out of LDS: the cells are counting-sorted by depth (a 2-byte order list),
+// every level is then a dense run of that list, and a finished cell leaves {comX, comY, mass} in LDS (12 B per cell)
+// for its parent one level up — no global round trip between a child and its parent, one barrier per non-empty level.
+// Each thread requests the child records of its NEXT cell from global memory before it evaluates the current one.
+// Same expressions in the same child order as bh_com_cell, so the bits are the same.
+constexpr int kBhComBlock = 1024;                             // 16 waves: twice the loads in flight of 8
+constexpr int kBhComLds = 11264;                              // cells: (3 x 4 + 2) B x 11264 = 154 KB of the CU's 160 KB LDS
+
+// this thread's next slot of the depth-sorted order list (levels from the deepest up); false when it has none left
+__device__ __forceinline__ bool bh_com_next(const int* lstart, const int* lend, int tid, int& d, int& s)
+{
+    s += kBhComBlock;
+    while (d >= 0 && s >= lend[d]) {
+        --d;
+        if (d >= 0) s = lstart[d] + tid;
+    }
+    return d >= 0;
+}
+
 __global__ __launch_bounds__(kBhComBlock) void bh_com_small_kernel(BhTree t, const BhCounters* __restrict__ ctr, int max_internal)
 {
     const int I = ctr->internal;
-    if (I > max_internal) return;
-    // each thread keeps the depths of its (at most kPer) cells in registers: the level loop then touches memory
-    // only for the cells of that level
-    constexpr int kPer = 32;                                    // max_internal <= kPer * kBhComBlock
-    uint8_t dl[kPer];
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-        const int c = threadIdx.x + k * kBhComBlock;
-        dl[k] = c < I ? t.depth[c] : (uint8_t)0xFF;
+    (void)max_internal;
+    __shared__ __align__(16) unsigned char lds[14 * kBhComLds];    // LDS path: x, y, mass, order; level loop: depths
+    __shared__ int lstart[kBhLevels + 1], lend[kBhLevels + 1];
+    const int tid = threadIdx.x;
+    if (I <= kBhComLds) {
+        float* lx = reinterpret_cast<float*>(lds);
+        float* ly = lx + kBhComLds;
+        float* lm = ly + kBhComLds;
+        unsigned short* order = reinterpret_cast<unsigned short*>(lm + kBhComLds);
+        // counting sort of the cells by depth, deepest level first (LDS atomics; a wave-aggregated variant with one
+        // atomic per wave and depth was measured slower: its ballot/shuffle loop costs more than the conflicts)
+        BhCounters* dbg = const_cast<BhCounters*>(ctr); (void)dbg;
+        BH_DBG_TICK(dbg, 8);
+        if (tid <= kBhLevels) lend[tid] = 0;
+        __syncthreads();
+        for (int c = tid; c < I; c += kBhComBlock) atomicAdd(&lend[t.depth[c]], 1);
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int d = kBhLevels - 1; d >= 0; --d) { lstart[d] = run; run += lend[d]; lend[d] = lstart[d]; }
+        }
+        __syncthreads();
+        for (int c = tid; c < I; c += kBhComBlock) order[atomicAdd(&lend[t.depth[c]], 1)] = (unsigned short)c;
+        __syncthreads();                                           // level d is order[lstart[d] .. lend[d])
+        BH_DBG_TICK(dbg, 9);
+        float4 a0, a1, a2, a3, n0, n1, n2, n3;
+        int cc0, cc1, cc2, cc3, self, cell, nc0, nc1, nc2, nc3, nself, ncell;
+#define BH_COM_FETCH(SLOT, CELL, A0, A1, A2, A3, C0, C1, C2, C3, SELF)                                 \
+        do {                                                                                           \
+            CELL = order[SLOT];                                                                        \
+            const float4* ap_ = t.A + 1 + 4 * CELL;                                                    \
+            const int2* bp_ = t.B + 1 + 4 * CELL;                                                      \
+            A0 = ap_[0]; A1 = ap_[1]; A2 = ap_[2]; A3 = ap_[3];                                        \
+            const int b0_ = bp_[0].x, b1_ = bp_[1].x, b2_ = bp_[2].x, b3_ = bp_[3].x;                  \
+            C0 = b0_ >= 0 ? (b0_ - 1) >> 2 : -1; C1 = b1_ >= 0 ? (b1_ - 1) >> 2 : -1;                  \
+            C2 = b2_ >= 0 ? (b2_ - 1) >> 2 : -1; C3 = b3_ >= 0 ? (b3_ - 1) >> 2 : -1;                  \
+            SELF = t.self[CELL];                                                                       \
+        } while (0)
+        int cd = kBhLevels - 1, cs = lstart[kBhLevels - 1] + tid - kBhComBlock;
+        bool have = bh_com_next(lstart, lend, tid, cd, cs);
+        if (have) BH_COM_FETCH(cs, cell, a0, a1, a2, a3, cc0, cc1, cc2, cc3, self);
+        int nd = cd, ns = cs;
+        bool have_next = have && bh_com_next(lstart, lend, tid, nd, ns);
+        if (have_next) BH_COM_FETCH(ns, ncell, n0, n1, n2, n3, nc0, nc1, nc2, nc3, nself);
+        BH_DBG_TICK(dbg, 10);
+        for (int lvl = kBhLevels - 1; lvl >= 0; --lvl) {
+            if (lend[lvl] == lstart[lvl]) continue;                // block-uniform
+            while (have && cd == lvl) {
+                float ms = 0.0f, sx = 0.0f, sy = 0.0f;
+#define BH_COM_ADD(CC, A)                                                                              \
+                do {                                                                                   \
+                    const float x_ = CC >= 0 ? lx[CC] : A.x, y_ = CC >= 0 ? ly[CC] : A.y;              \
+                    const float m_ = CC >= 0 ? lm[CC] : A.z;                                           \
+                    ms = ms + m_; sx = __builtin_fmaf(x_, m_, sx); sy = __builtin_fmaf(y_, m_, sy);    \
+                } while (0)
+                BH_COM_ADD(cc0, a0);                            // benchmark.cpp:126-135 in child order, as bh_com_cell
+                BH_COM_ADD(cc1, a1);
+                BH_COM_ADD(cc2, a2);
+                BH_COM_ADD(cc3, a3);
+#undef BH_COM_ADD
+                float cx = 0.0f, cy = 0.0f;
+                if (ms > 0.0f) {                                // benchmark.cpp:137-141
+                    if (t.com_reciprocal) { const float inv = 1.0f / ms; cx = sx * inv; cy = sy * inv; }
+                    else                  { cx = sx / ms; cy = sy / ms; }
+                }
+                lx[cell] = cx; ly[cell] = cy; lm[cell] = ms;
+                float* rec = reinterpret_cast<float*>(t.A + self);
+                rec[0] = cx; rec[1] = cy; rec[2] = ms;
+                have = have_next; cd = nd; cs = ns;
+                a0 = n0; a1 = n1; a2 = n2; a3 = n3; cc0 = nc0; cc1 = nc1; cc2 = nc2; cc3 = nc3; self = nself; cell = ncell;
+                if (have_next) {
+                    have_next = bh_com_next(lstart, lend, tid, nd, ns);
+                    if (have_next) BH_COM_FETCH(ns, ncell, n0, n1, n2, n3, nc0, nc1, nc2, nc3, nself);
+                }
+            }
+            bh_lds_barrier();                                      // level lvl is in LDS before level lvl-1 reads it
+        }
+#undef BH_COM_FETCH
+        BH_DBG_TICK(dbg, 11);
+        return;
+    }
+    // Larger trees: level loop over global memory (depths staged in LDS while they fit).  Slow — the host enqueues
+    // this kernel only when the previous build's tree was small (nbody_capi.hip), so this is the safety net for a
+    // tree that has just outgrown the LDS path, not a path anyone should live on.
+    const bool staged = I <= (int)sizeof(lds);
+    uint8_t* dl = lds;
+    if (staged) {
+        for (int c = threadIdx.x; c < I; c += kBhComBlock) dl[c] = t.depth[c];
+        __syncthreads();
     }
     for (int d = kBhLevels - 1; d >= 0; --d) {                 // a level without cells costs one barrier
-#pragma unroll
-        for (int k = 0; k < kPer; ++k)
-            if (dl[k] == d) bh_com_cell(t, threadIdx.x + k * kBhComBlock);
+#pragma unroll 4
+        for (int c = threadIdx.x; c < I; c += kBhComBlock)
+            if ((staged ? dl[c] : t.depth[c]) == d) bh_com_cell(t, c);
         __syncthreads();        // one workgroup: a barrier (with its LDS/global fence) orders level d before d-1
     }
 }
@@ -781,6 +1062,273 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
         atomicAdd(&w.ctr->visits, sv);
         atomicAdd(&w.ctr->accepts, sa);
         atomicAdd(&w.ctr->wave_iters, si);
+    }
+}
+
+// Wide walk (small N) ---------------------------------------------------------------------------------------------
+// Below ~32 768 bodies the walk above is a latency chain: one node record per visit, ~500 dependent visits per group,
+// ~0.5 us each, on a chip that is mostly idle (N = 10 000 is 1250 groups for 1024 SIMDs).  Here ONE WAVE takes ONE
+// group and all 64 lanes work on it: 8 slots x the group's 8 targets, every slot testing a different pending node.
+//
+//   pass 1  traversal, order-free: pop up to 16 pending nodes (2 per slot), load their records together, take the
+//           reference's vote per slot (8-bit ballot field), append accepted nodes to a list and push the children of
+//           opened ones.  Every pending node carries its DFS position as a path key — digit 3-q per level, because the
+//           reference pops child 3 first (benchmark.cpp:244, :272-274) — so the ORDER in which nodes are tested is free;
+//   sort    the accepted (key, node) pairs by key in LDS (bitonic): now they are in the reference's visiting order;
+//   pass 2  8 accepted nodes at a time, one per slot: node kernel (benchmark.cpp:188-225) for the 8 targets, terms
+//           through LDS, every lane adds the 8 terms of its target IN ORDER.
+//
+// Same arithmetic per (node, target) and the same summation order as bh_walk_kernel, so accelerations and the
+// visit/accept counters are bit-identical to it and to the oracle.  The lists live in LDS and are bounded; when a
+// traversal outgrows them it is abandoned and its root is split into its four children, each walked on its own, in
+// DFS order (a node whose lists overflow was opened, so this is exactly what the reference does with it).
+constexpr int kWideStack = 512;      // pending nodes
+constexpr int kWideAccepts = 1024;   // accepted nodes of one traversal
+constexpr int kWidePerSlot = 4;      // nodes tested per slot per iteration of pass 1
+constexpr int kWideRound = 2;        // nodes per slot per round of pass 2
+
+// Bitonic sort of 64 * R (key, node) pairs held in registers, element index = lane * R + r: strides below R are
+// compare-exchanges between a lane's own registers, strides of R and more go through cross-lane shuffles
+// (ds_bpermute, no LDS traffic, no barriers).  An order of magnitude faster than the same network through LDS.
+template <int R, int J>
+__device__ __forceinline__ void bh_wide_sort_regs(unsigned long long (&k)[R], int (&v)[R], int kk, int lane)
+{
+    if constexpr (J < R) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if ((r & J) == 0) {
+                constexpr int dummy = 0; (void)dummy;
+                const int q = r | J;
+                const bool up = ((lane * R + r) & kk) == 0;
+                const bool sw = (k[r] > k[q]) == up;
+                const unsigned long long ka = sw ? k[q] : k[r], kb = sw ? k[r] : k[q];
+                const int va = sw ? v[q] : v[r], vb = sw ? v[r] : v[q];
+                k[r] = ka; k[q] = kb; v[r] = va; v[q] = vb;
+            }
+        }
+    }
+}
+
+template <int R>
+__device__ __noinline__ void bh_wide_sort(unsigned long long* __restrict__ akey, int* __restrict__ anode, int lane)
+{
+    unsigned long long k[R];
+    int v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { k[r] = akey[lane * R + r]; v[r] = anode[lane * R + r]; }
+#pragma unroll 1
+    for (int kk = 2; kk <= 64 * R; kk <<= 1) {
+#pragma unroll 1
+        for (int j = kk >> 1; j >= R; j >>= 1) {           // strides of R and more: the partner is in another lane
+            const int lj = j / R;
+            const bool want_min = ((lane & lj) == 0) == (((lane * R) & kk) == 0);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const unsigned long long ok = __shfl_xor(k[r], lj, 64);
+                const int ov = __shfl_xor(v[r], lj, 64);
+                const bool take = want_min ? ok < k[r] : ok > k[r];
+                k[r] = take ? ok : k[r];
+                v[r] = take ? ov : v[r];
+            }
+        }
+        if (kk >= 16) bh_wide_sort_regs<R, 8>(k, v, kk, lane);   // strides below R: the lane's own registers
+        if (kk >= 8) bh_wide_sort_regs<R, 4>(k, v, kk, lane);
+        if (kk >= 4) bh_wide_sort_regs<R, 2>(k, v, kk, lane);
+        bh_wide_sort_regs<R, 1>(k, v, kk, lane);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) anode[lane * R + r] = v[r];
+}
+
+template <bool kFast>
+__global__ __launch_bounds__(64) void bh_walk_wide_kernel(const BhWalkArgs w)
+{
+#pragma clang fp contract(off)
+    __shared__ unsigned long long pkey[kWideStack];
+    __shared__ int pnode[kWideStack];
+    __shared__ unsigned long long akey[kWideAccepts];
+    __shared__ int anode[kWideAccepts];
+    __shared__ float termx[8 * kWideRound][8], termy[8 * kWideRound][8];
+    __shared__ int tasks[128];
+    const int lane = threadIdx.x, slot = lane >> 3, t = lane & 7;
+    const int i = w.i_begin + (int)blockIdx.x * 8 + t;
+    const bool live = i < w.i_end;
+    const int ic = live ? i : w.i_end - 1;
+    const float xi = w.px[ic], yi = w.py[ic], ri = w.radius[ic];
+    const float eps = 1e-6f, soft2 = 0.001f * 0.001f;
+    const float vote_margin = 4e-6f * w.theta;
+    const unsigned long long below_me = (1ull << lane) - 1ull;
+    const unsigned long long below_slot = (1ull << (slot * 8)) - 1ull;
+    float ax = 0.0f, ay = 0.0f;
+    unsigned visits = 0, accepts = 0;                    // wave-uniform
+#ifdef NBODY_WIDE_TIMING                                 // developer build: 100 MHz ticks per phase instead of results
+    unsigned long long tk0 = __builtin_amdgcn_s_memrealtime(), tk1 = 0, tk2 = 0, tk3 = 0, tkx;
+    unsigned iters = 0;
+#define WIDE_TICK(acc) do { tkx = __builtin_amdgcn_s_memrealtime(); acc += tkx - tk0; tk0 = tkx; } while (0)
+#else
+#define WIDE_TICK(acc) do { } while (0)
+#endif
+    int ntask = 1;
+    if (lane == 0) tasks[0] = 0;
+    __syncthreads();
+    while (ntask > 0) {
+        const int root = tasks[--ntask];
+        // ---- pass 1: which nodes does the reference accept below `root`? ----
+        int sp = 1, na = 0;
+        unsigned tv = 0;
+        bool overflow = false;
+        if (lane == 0) { pnode[0] = root; pkey[0] = 1ull; }
+        __syncthreads();
+        while (sp > 0 && !overflow) {
+#ifdef NBODY_WIDE_TIMING
+            ++iters;
+#endif
+            int node[kWidePerSlot];
+            unsigned long long key[kWidePerSlot];
+            bool act[kWidePerSlot];
+            const int take = sp < 8 * kWidePerSlot ? sp : 8 * kWidePerSlot;
+#pragma unroll
+            for (int u = 0; u < kWidePerSlot; ++u) {
+                const int e = sp - 1 - (u * 8 + slot);
+                act[u] = u * 8 + slot < take;
+                node[u] = act[u] ? pnode[e] : 0;
+                key[u] = act[u] ? pkey[e] : 1ull;
+            }
+            sp -= take;
+            tv += (unsigned)take;
+            float4 a[kWidePerSlot];
+            int2 b[kWidePerSlot];
+#pragma unroll
+            for (int u = 0; u < kWidePerSlot; ++u) { a[u] = w.A[node[u]]; b[u] = w.B[node[u]]; }
+            __syncthreads();                              // every lane has read its entries before anyone overwrites them
+#pragma unroll
+            for (int u = 0; u < kWidePerSlot; ++u) {
+                const float dx = a[u].x - xi, dy = a[u].y - yi;               // benchmark.cpp:254-255
+                const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+                // The vote is a boolean: the hardware's 1-ulp sqrt/rcp decide it unless the ratio is within 4e-6
+                // (relative, > 10x their error bound) of theta, in which case the wave redoes the node with the IEEE
+                // expressions of benchmark.cpp:256-262 — same decisions as the oracle, a fifth of the instructions.
+                const float q = a[u].w * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(d2) + eps);
+                bool far = q < w.theta;
+                if (__any(__builtin_fabsf(q - w.theta) <= vote_margin))
+                    far = (a[u].w / (__builtin_sqrtf(d2) + eps)) < w.theta;
+                const unsigned long long fm = __ballot(far || !live);
+                const bool all_far = ((fm >> (slot * 8)) & 0xFFull) == 0xFFull;
+                const bool massive = act[u] && a[u].z != 0.0f;                 // :248
+                const bool accept = massive && (b[u].x < 0 || all_far);        // :266
+                const bool open = massive && !accept;
+                const unsigned long long am = __ballot(accept && t == 0);
+                const int apos = na + __popcll(am & below_me);
+                if (accept && t == 0 && apos < kWideAccepts) {
+                    akey[apos] = key[u] << (__builtin_clzll(key[u]) - 1);      // left-aligned: sentinel at bit 62
+                    anode[apos] = node[u];
+                }
+                na += __popcll(am);
+                const unsigned long long om = __ballot(open && t == 0);
+                const int base = sp + 4 * __popcll(om & below_slot);
+                if (open && t < 4 && base + t < kWideStack) {
+                    pnode[base + t] = b[u].x + t;                              // children 0..3 (:272-274)
+                    pkey[base + t] = (key[u] << 2) | (unsigned long long)(3 - t);   // popped 3 first (:244)
+                }
+                sp += 4 * __popcll(om);
+            }
+            overflow = sp > kWideStack || na > kWideAccepts;
+            __syncthreads();
+        }
+        if (overflow) {
+            // `root` was opened (its lists grew): count its visit and walk its four children one by one, 3 first
+            visits += 1;
+            const int cb = w.B[root].x;
+            if (lane < 4) tasks[ntask + lane] = cb + lane;
+            ntask += 4;
+            __syncthreads();
+            continue;
+        }
+        visits += tv;
+        accepts += (unsigned)na;
+        WIDE_TICK(tk1);
+        // ---- sort the accepted nodes into the reference's visiting order ----
+        if (na > 1) {
+            int P = 64;
+            while (P < na) P <<= 1;
+            for (int e = na + lane; e < P; e += 64) akey[e] = ~0ull;
+            __syncthreads();
+            switch (P) {
+                case 64:  bh_wide_sort<1>(akey, anode, lane); break;
+                case 128: bh_wide_sort<2>(akey, anode, lane); break;
+                case 256: bh_wide_sort<4>(akey, anode, lane); break;
+                case 512: bh_wide_sort<8>(akey, anode, lane); break;
+                default:  bh_wide_sort<16>(akey, anode, lane); break;
+            }
+            __syncthreads();
+        }
+        WIDE_TICK(tk2);
+        // ---- pass 2: node kernel in that order, 8 * kWideRound nodes per round ----
+        constexpr int kRound = 8 * kWideRound;
+        float4 a[kWideRound];
+        int2 b[kWideRound];
+#pragma unroll
+        for (int u = 0; u < kWideRound; ++u) {
+            const int nd = u * 8 + slot < na ? anode[u * 8 + slot] : 0;
+            a[u] = w.A[nd]; b[u] = w.B[nd];
+        }
+        for (int c0 = 0; c0 < na; c0 += kRound) {
+            float4 an[kWideRound];
+            int2 bn[kWideRound];
+#pragma unroll
+            for (int u = 0; u < kWideRound; ++u) {                             // next round's records are requested
+                const int e = c0 + kRound + u * 8 + slot;                      // before this round's arithmetic
+                const int nd = e < na ? anode[e] : 0;
+                an[u] = w.A[nd]; bn[u] = w.B[nd];
+            }
+#pragma unroll
+            for (int u = 0; u < kWideRound; ++u) {
+                const float dx = a[u].x - xi, dy = a[u].y - yi;
+                const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+                float d, inv, f;
+                if constexpr (kFast) {
+                    d = __builtin_amdgcn_sqrtf(d2);
+                    inv = __builtin_amdgcn_rcpf(d + eps);
+                    const float sd = __builtin_fmaxf(d, ri);
+                    f = a[u].z * __builtin_amdgcn_rcpf(__builtin_fmaf(sd, sd, soft2));
+                } else {
+                    d = __builtin_sqrtf(d2);
+                    const float sd = __builtin_fmaxf(d, ri);                   // :201-202
+                    f = a[u].z / __builtin_fmaf(sd, sd, soft2);                // :203-209
+                    inv = 1.0f / (d + eps);                                    // :212-213
+                }
+                const bool self = b[u].y == i;                                 // :197-198
+                termx[u * 8 + slot][t] = self ? 0.0f : (dx * inv) * f;
+                termy[u * 8 + slot][t] = self ? 0.0f : (dy * inv) * f;
+            }
+            __syncthreads();
+            const int nv = na - c0 < kRound ? na - c0 : kRound;
+            for (int u = 0; u < nv; ++u) { ax = ax + termx[u][t]; ay = ay + termy[u][t]; }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < kWideRound; ++u) { a[u] = an[u]; b[u] = bn[u]; }
+        }
+        WIDE_TICK(tk3);
+    }
+#ifdef NBODY_WIDE_TIMING
+    if (t == 0) { ax = (float)tk1; ay = (float)tk2; } else if (t == 1) { ax = (float)tk3; ay = (float)iters; }
+#endif
+    if (live && slot == 0) {
+        w.ax[i] = ax;
+        w.ay[i] = ay;
+        if (w.advance) {
+            const float u = w.vx[i], v = w.vy[i];
+            w.px[i] = __builtin_fmaf(u, w.dt, xi);          // benchmark.cpp:389-390 from the OLD velocity
+            w.py[i] = __builtin_fmaf(v, w.dt, yi);
+            w.vx[i] = __builtin_fmaf(ax, w.dt, u);          // :393-394
+            w.vy[i] = __builtin_fmaf(ay, w.dt, v);
+        }
+    }
+    if (lane == 0) {
+        w.grp_visits[(w.i_begin >> 3) + blockIdx.x] = (int)visits;
+        w.grp_accepts[(w.i_begin >> 3) + blockIdx.x] = (int)accepts;
+        atomicAdd(&w.ctr->visits, (unsigned long long)visits);
+        atomicAdd(&w.ctr->accepts, (unsigned long long)accepts);
     }
 }
 

@@ -55,6 +55,7 @@ struct Profiler {
 };
 
 constexpr int kMaxSlices = 64;
+constexpr int kBhWideMaxGroups = 4096;      // <= 32 768 targets: the walk takes one wave per group (measured crossover)
 constexpr size_t kMaxEventsPerClass = 4096;
 
 }  // namespace
@@ -115,6 +116,7 @@ struct nbody_ctx {
         BhCounters* ctr = nullptr;
         int *overflow_host = nullptr, *overflow_dev = nullptr;   // pinned, device-mapped word: the last build's overflow flag
         int *grp_visits = nullptr, *grp_accepts = nullptr;   // per group of 8 bodies, written by every walk
+        int com_lds_pass = -1;                       // which centre-of-mass pass the last build enqueued (-1: none yet)
         void *sort_tmp = nullptr, *scan_tmp = nullptr;
         size_t sort_bytes = 0, scan_bytes = 0;
         int64_t node_cap = 0;
@@ -229,6 +231,17 @@ int enqueue_integrate(nbody_ctx* ctx, int advance)
 }
 
 
+// 1: the one-workgroup LDS pass, 0: one launch per depth (see enqueue_bh_build).  Hint = the previous build's cell
+// count, with hysteresis so that a tree hovering at the limit does not re-capture the step graph every step.
+int choose_com_pass(nbody_ctx* ctx)
+{
+    auto& b = ctx->bh;
+    if (b.tree.cap_internal <= kBhComLds) return 1;
+    const int hint = b.overflow_host[1] > 0 ? b.overflow_host[1] : (int)(0.73 * ctx->cfg.num_bodies);
+    if (b.com_lds_pass == 1) return hint <= kBhComLds ? 1 : 0;
+    return hint <= kBhComLds - kBhComLds / 8 ? 1 : 0;
+}
+
 // Barnes-Hut step = build (keys -> sort -> cells -> nodes -> centre of mass) + walk, benchmark.cpp:354-403.
 int enqueue_bh_build(nbody_ctx* ctx)
 {
@@ -246,35 +259,46 @@ int enqueue_bh_build(nbody_ctx* ctx)
         bh_reset_kernel<<<1, 64, 0, s>>>(b.ctr, 1e-30f);
         bh_bounds_kernel<<<dim3(grid_n.x < 1024u ? grid_n.x : 1024u), blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr);
     }
+    const bool fused = n <= kBhSmallMax && b.gcap <= kBhSmallGhosts && !std::getenv("NBODY_BH_NO_FUSE");
     bh_keys_kernel<<<grid_n, blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr, ctx->cfg.spread, adaptive ? 0 : 1, b.keys, b.vals, b.tie,
-                                          b.gkeys, b.gvals, b.gcap, b.tie_table, b.tie_table_size);
+                                          b.gkeys, b.gvals, b.gcap, b.tie_table, b.tie_table_size, fused ? 1 : 0);
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, b.keys, b.keys_sorted, b.vals, b.vals_sorted, n,
                                                0, 64, s));
-    bh_valid_kernel<<<1, 64, 0, s>>>(b.keys_sorted, n, b.ctr);
     // bodies exactly on a split line get a second instance (inclusive bounds, benchmark.cpp:83-85)
     BhTies ties{b.gkeys, b.gvals, b.gfx, b.gfy, b.gld, b.glo, b.ghi, b.gpos, b.pld, b.tie_table, b.tie_table_size - 1, b.gcap};
-    bh_ties_kernel<<<grid_n, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties);
-    bh_tie_fixpoint_kernel<<<1, kBhFixBlock, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties);
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.gsort_tmp, b.gsort_bytes, b.gkeys, b.gkeys_sorted, b.gvals, b.gvals_sorted,
-                                               b.gcap, 0, 64, s));
-    bh_merge_kernel<<<grid_m, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, n, b.gkeys_sorted, b.gvals_sorted, b.gcap,
-                                           b.keys_merged, b.vals_merged, b.ctr);
-    bh_count_kernel<<<grid_m, blk, 0, s>>>(b.keys_merged, nm, b.ctr, b.cnt);
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b.scan_tmp, b.scan_bytes, b.cnt, b.base, nm, s));
+    if (fused) {
+        // small N: valid count, split-line instances, their sort, merge, cell count, scan and owners in one launch
+        bh_prep_small_kernel<<<1, kBhFixBlock, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties, n,
+                                                       b.gkeys_sorted, b.gvals_sorted, b.keys_merged, b.vals_merged, b.cnt, b.base,
+                                                       b.owner, b.tree.cap_internal);
+    } else {
+        bh_valid_kernel<<<1, 64, 0, s>>>(b.keys_sorted, n, b.ctr);
+        bh_ties_kernel<<<grid_n, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties);
+        bh_tie_fixpoint_kernel<<<1, kBhFixBlock, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties);
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.gsort_tmp, b.gsort_bytes, b.gkeys, b.gkeys_sorted, b.gvals, b.gvals_sorted,
+                                                   b.gcap, 0, 64, s));
+        bh_merge_kernel<<<grid_m, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, n, b.gkeys_sorted, b.gvals_sorted, b.gcap,
+                                               b.keys_merged, b.vals_merged, b.ctr);
+        bh_count_kernel<<<grid_m, blk, 0, s>>>(b.keys_merged, nm, b.ctr, b.cnt);
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b.scan_tmp, b.scan_bytes, b.cnt, b.base, nm, s));
+        bh_owner_kernel<<<grid_m, blk, 0, s>>>(b.cnt, b.base, nm, b.ctr, b.owner, b.tree.cap_internal);
+    }
     const dim3 grid_c((b.tree.cap_internal + kBhBlock - 1) / kBhBlock);
-    bh_owner_kernel<<<grid_m, blk, 0, s>>>(b.cnt, b.base, nm, b.ctr, b.owner, b.tree.cap_internal);
     bh_nodes_kernel<<<grid_c, blk, 0, s>>>(b.keys_merged, b.vals_merged, b.cnt, b.base, b.owner, nm, ctx->m, ctx->px, ctx->py,
-                                           b.tree, b.ctr, b.overflow_dev);
-    // centre of mass: ONE single-workgroup launch covers trees of <= kComSmall internal cells (the cell count is
-    // only known on the device, so the kernels decide there which of the two paths runs); per-depth launches
-    // otherwise.  Contexts whose pool cannot exceed kComSmall cells never enqueue the per-depth launches.
-    constexpr int kComSmall = 32768;
-    const bool maybe_small = n <= 8 * kComSmall;
-    if (maybe_small) bh_com_small_kernel<<<1, kBhComBlock, 0, s>>>(b.tree, b.ctr, kComSmall);
-    if (b.tree.cap_internal > kComSmall) {
+                                           b.tree, b.ctr, b.overflow_dev, fused ? b.keys_sorted : nullptr,
+                                           fused ? b.vals_sorted : nullptr);
+    // centre of mass.  Two passes, each correct for ANY tree: one workgroup with the results in LDS (fast up to
+    // kBhComLds cells, a slow level loop beyond) or one launch per depth (31 launches of ~4.5 us, the only sane way for
+    // a big tree).  Which one is enqueued is a HOST decision, so it is taken from the cell count of the previous
+    // build (the node kernel leaves it in host-mapped memory; 0.73 cells per body for the reference's disc when there
+    // is no previous build).  A captured graph keeps its choice until the hint crosses the threshold.
+    b.com_lds_pass = choose_com_pass(ctx);
+    if (b.com_lds_pass) {
+        bh_com_small_kernel<<<1, kBhComBlock, 0, s>>>(b.tree, b.ctr, 0);
+    } else {
         const dim3 grid_com((unsigned)((b.tree.cap_internal + 4 * kBhBlock - 1) / (4 * kBhBlock)));
         for (int d = kBhLevels - 1; d >= 0; --d)
-            bh_com_kernel<<<grid_com, blk, 0, s>>>(b.tree, b.ctr, d, maybe_small ? kComSmall : -1);
+            bh_com_kernel<<<grid_com, blk, 0, s>>>(b.tree, b.ctr, d, -1);
     }
     HIP_TRY(hipGetLastError());
     return profile_end(ctx, 2, ep);
@@ -296,11 +320,21 @@ int enqueue_bh_walk(nbody_ctx* ctx, int advance)
     EventPair* ep;
     int rc = profile_begin(ctx, 0, &ep);
     if (rc) return rc;
-    w.lanes_used = 8 * bh_walk_groups_per_wave(nt);
-    const int per_block = (kBhBlock / 64) * w.lanes_used;      // targets per workgroup
-    const dim3 grid((nt + per_block - 1) / per_block), blk(kBhBlock);
-    if (ctx->cfg.bh_fast_math) bh_walk_kernel<true><<<grid, blk, 0, ctx->stream>>>(w);
-    else                       bh_walk_kernel<false><<<grid, blk, 0, ctx->stream>>>(w);
+    // Few groups: one wave per group, all 64 lanes on it (bh_walk_wide_kernel); many: 8 groups per wave.
+    const int groups = (nt + 7) / 8;
+    bool wide = groups <= kBhWideMaxGroups;
+    if (const char* e = std::getenv("NBODY_BH_WIDE")) wide = e[0] == '1';       // developer A/B switch
+    if (wide) {
+        w.lanes_used = 8;
+        if (ctx->cfg.bh_fast_math) bh_walk_wide_kernel<true><<<dim3(groups), dim3(64), 0, ctx->stream>>>(w);
+        else                       bh_walk_wide_kernel<false><<<dim3(groups), dim3(64), 0, ctx->stream>>>(w);
+    } else {
+        w.lanes_used = 8 * bh_walk_groups_per_wave(nt);
+        const int per_block = (kBhBlock / 64) * w.lanes_used;      // targets per workgroup
+        const dim3 grid((nt + per_block - 1) / per_block), blk(kBhBlock);
+        if (ctx->cfg.bh_fast_math) bh_walk_kernel<true><<<grid, blk, 0, ctx->stream>>>(w);
+        else                       bh_walk_kernel<false><<<grid, blk, 0, ctx->stream>>>(w);
+    }
     HIP_TRY(hipGetLastError());
     return profile_end(ctx, 0, ep);
 }
@@ -484,8 +518,8 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
         HIP_TRY_C(hipMalloc((void**)&b.tree.self, sizeof(int) * (size_t)b.tree.cap_internal));
         HIP_TRY_C(hipMalloc((void**)&b.ctr, sizeof(BhCounters)));
         HIP_TRY_C(hipMemset(b.ctr, 0, sizeof(BhCounters)));
-        HIP_TRY_C(hipHostMalloc((void**)&b.overflow_host, sizeof(int), hipHostMallocMapped));
-        *b.overflow_host = 0;
+        HIP_TRY_C(hipHostMalloc((void**)&b.overflow_host, 2 * sizeof(int), hipHostMallocMapped));
+        b.overflow_host[0] = b.overflow_host[1] = 0;           // [0] overflow flag, [1] internal cells of the last build
         HIP_TRY_C(hipHostGetDevicePointer((void**)&b.overflow_dev, b.overflow_host, 0));
         HIP_TRY_C(hipMalloc((void**)&b.grp_visits, sizeof(int) * ((size_t)n / 8 + 1)));
         HIP_TRY_C(hipMalloc((void**)&b.grp_accepts, sizeof(int) * ((size_t)n / 8 + 1)));
@@ -653,6 +687,9 @@ namespace {
 
 int enqueue_one_step(nbody_ctx* ctx);
 
+void drop_step_graph(nbody_ctx* ctx);
+}  // namespace
+namespace {
 void drop_step_graph(nbody_ctx* ctx)
 {
     if (ctx->step_graph) (void)hipGraphExecDestroy(ctx->step_graph);
@@ -665,6 +702,8 @@ void drop_step_graph(nbody_ctx* ctx)
 bool ensure_step_graph(nbody_ctx* ctx)
 {
     if (!ctx->cfg.use_barnes_hut || ctx->prof.on || ctx->graph_failed || std::getenv("NBODY_NO_GRAPH")) return false;
+    // the captured build holds one of the two centre-of-mass passes: capture again when the tree has outgrown it
+    if (ctx->step_graph && ctx->bh.com_lds_pass != choose_com_pass(ctx)) drop_step_graph(ctx);
     if (ctx->step_graph && ctx->step_graph_stream == ctx->stream) return true;
     drop_step_graph(ctx);
     hipGraph_t graph = nullptr;
@@ -980,6 +1019,15 @@ int nbody_bh_counters(nbody_ctx* ctx, int64_t out[2])
     HIP_TRY(hipMemcpy(&h, ctx->bh.ctr, sizeof(h), hipMemcpyDeviceToHost));
     out[0] = (int64_t)h.visits;
     out[1] = (int64_t)h.accepts;
+#ifdef NBODY_WIDE_TIMING
+    if (std::getenv("NBODY_DEBUG")) {
+        std::fprintf(stderr, "[nbody] prep phases (us): valid+ties %.2f fixpoint %.2f ghosts/merge %.2f count %.2f scan %.2f write %.2f | "
+                             "com: sort-by-depth %.2f first fetches %.2f levels %.2f\n",
+                     (h.dbg[1] - h.dbg[0]) * 0.01, (h.dbg[2] - h.dbg[1]) * 0.01, (h.dbg[3] - h.dbg[2]) * 0.01, (h.dbg[4] - h.dbg[3]) * 0.01,
+                     (h.dbg[5] - h.dbg[4]) * 0.01, (h.dbg[6] - h.dbg[5]) * 0.01, (h.dbg[9] - h.dbg[8]) * 0.01, (h.dbg[10] - h.dbg[9]) * 0.01,
+                     (h.dbg[11] - h.dbg[10]) * 0.01);
+    }
+#endif
     if (std::getenv("NBODY_DEBUG"))
         std::fprintf(stderr, "[nbody] walk: %llu group-visits in %llu wave iterations: %.1f %% of the 8 group slots busy; "
                              "%d second instances (bodies on split lines), %d valid instances, %d internal cells\n",
