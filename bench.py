@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--theta", type=float, default=1.0)
     ap.add_argument("--bh-fast-math", action="store_true",
                     help="bh workload: 1-ulp hardware sqrt/rcp in the walk (same votes, terms differ by a few ulp)")
+    ap.add_argument("--bh-sorted", action="store_true",
+                    help="bh workload: groups of 8 in the tree's own space-filling order, vote at 0.7 theta (ref_compat 0; not the reference's grouping)")
     args = ap.parse_args()
     if os.environ.get("NBODY_DEBUG") or os.environ.get("NBODY_DIST_BACKEND", "nccl") != "nccl":
         # a stalled rank reports where it stands instead of hanging its launcher (always on in the gloo rehearsal)
@@ -207,7 +209,7 @@ def main():
 
     bh = args.workload == "bh"
     sim = ShardedSim(pkg, n, rank, world, device=local_rank, dt=0.05, dist=dist, useBarnesHut=bh, theta=args.theta,
-                     bh_fast_math=bh and args.bh_fast_math)
+                     bh_fast_math=bh and args.bh_fast_math, **(dict(bh_sorted=True, ref_compat=0) if bh and args.bh_sorted else {}))
     sim.upload(*bodies)
     my_targets = owned_targets(n, sim.spans, rank)
 
@@ -261,7 +263,9 @@ def main():
                                    f"seeded disc (benchmark.cpp:317-339, seed 12345); timed: steps 1-{args.steps} of that state "
                                    f"(warm-up ran on the same context, then the initial state was uploaded again)",
                        "num_bodies": n, "parallelism": f"tree replicated, walk i-sharded x{world}",
-                       "arithmetic": "hardware sqrt/rcp, exact vote" if args.bh_fast_math else "IEEE (bit-identical to the oracle)"},
+                       "arithmetic": "hardware sqrt/rcp, exact vote" if args.bh_fast_math else "IEEE (bit-identical to the oracle)",
+                       "grouping": "bh_sorted: 8 consecutive bodies of the tree's quadrant-path order, vote at 0.7 theta" if args.bh_sorted
+                                   else "reference: 8 consecutive body indices (benchmark.cpp:366-380)"},
             "roofline": {"bound": "hbm", "achieved": walk_gbs, "peak": 8000.0, "unit": "GB/s", "frac": walk_gbs / 8000.0,
                          "traffic": None, "kernel": "bh_walk_kernel", "kernel_ms": walk_ms, "clock": clock,
                          "build_ms": build_ms / max(1, build_launches), "launches": int(force_launches),

@@ -36,7 +36,7 @@ class Config(C.Structure):
                 ("theta", C.c_float), ("use_barnes_hut", C.c_int32), ("use_parallel", C.c_int32),
                 ("ref_compat", C.c_int32), ("device", C.c_int32), ("shard_begin", C.c_int32),
                 ("shard_count", C.c_int32), ("force_variant", C.c_int32), ("adaptive_box", C.c_int32), ("bh_fast_math", C.c_int32),
-                ("reserved", C.c_int32 * 2)]
+                ("bh_sorted", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class NBodyError(RuntimeError):
@@ -164,12 +164,13 @@ class NBodySim:
 
     def __init__(self, numBodies, *, spread=400.0, mass=1000.0, dt=0.05, theta=1.0, useBarnesHut=False,
                  useParallel=True, ref_compat=True, device=-1, shard=None, force_variant=0, adaptive_box=False,
-                 bh_fast_math=False):
+                 bh_fast_math=False, bh_sorted=False):
         cfg = default_config()
         cfg.num_bodies, cfg.spread, cfg.mass, cfg.dt, cfg.theta = int(numBodies), spread, mass, dt, theta
         cfg.use_barnes_hut, cfg.use_parallel = int(bool(useBarnesHut)), int(bool(useParallel))
         cfg.ref_compat, cfg.device, cfg.force_variant = int(ref_compat), int(device), int(force_variant)
         cfg.adaptive_box, cfg.bh_fast_math = int(bool(adaptive_box)), int(bool(bh_fast_math))
+        cfg.bh_sorted = int(bool(bh_sorted))
         if shard is not None:
             cfg.shard_begin, cfg.shard_count = int(shard[0]), int(shard[1])
         self.cfg = cfg

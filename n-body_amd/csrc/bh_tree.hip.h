@@ -923,6 +923,7 @@ struct BhWalkArgs {
     int lanes_used;                  // 8 x groups per wave (64, 32, 16 or 8): see bh_walk_groups_per_wave()
     int* __restrict__ grp_visits;    // [n/8 + 1] per group of 8 bodies (index = first body / 8): nodes popped and
     int* __restrict__ grp_accepts;   //           nodes accepted by this walk (parity hook, nbody_bh_group_counters)
+    const int* __restrict__ order;   // bh_sorted: walk position -> body (the build's sorted order); nullptr: identity
 };
 
 // Groups per wave.  8 (all 64 lanes) is the throughput shape.  With few groups the walk is a latency chain and the
@@ -955,10 +956,12 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     const int tid = threadIdx.x;
     // wave v of the grid walks groups [v*G, (v+1)*G), G = lanes_used/8, on its first lanes_used lanes
     const int lane = tid & 63;
-    const int i = w.i_begin + (blockIdx.x * (kBhBlock / 64) + (tid >> 6)) * w.lanes_used + lane;
-    const bool live = lane < w.lanes_used && i < w.i_end;
-    const int ic = live ? i : w.i_end - 1;
-    const float xi = w.px[ic], yi = w.py[ic], ri = w.radius[ic];
+    // pos: position in walk order (groups are 8 consecutive positions); i: the body there
+    const int pos = w.i_begin + (blockIdx.x * (kBhBlock / 64) + (tid >> 6)) * w.lanes_used + lane;
+    const bool live = lane < w.lanes_used && pos < w.i_end;
+    const int pc = live ? pos : w.i_end - 1;
+    const int i = w.order ? w.order[pc] : pc;
+    const float xi = w.px[i], yi = w.py[i], ri = w.radius[i];
     const int grp_shift = (tid & 63) & ~7;                      // first lane of this group inside the wave
     const float eps = 1e-6f, soft2 = 0.001f * 0.001f;
     const float vote_margin = 4e-6f * w.theta;
@@ -1051,7 +1054,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     }
 
     // counters: one representative lane per group
-    if ((tid & 7) == 0 && i < w.i_end && lane < w.lanes_used) { w.grp_visits[i >> 3] = (int)visits; w.grp_accepts[i >> 3] = (int)accepts; }
+    if ((tid & 7) == 0 && live) { w.grp_visits[pos >> 3] = (int)visits; w.grp_accepts[pos >> 3] = (int)accepts; }
     unsigned long long v = (tid & 7) == 0 ? visits : 0, acc = (tid & 7) == 0 ? accepts : 0;
     for (int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); acc += __shfl_down(acc, off, 64); }
     if ((tid & 63) == 0) { red[0][tid >> 6] = v; red[1][tid >> 6] = acc; red[2][tid >> 6] = iters; }
@@ -1151,10 +1154,11 @@ __global__ __launch_bounds__(64) void bh_walk_wide_kernel(const BhWalkArgs w)
     __shared__ float termx[8 * kWideRound][8], termy[8 * kWideRound][8];
     __shared__ int tasks[128];
     const int lane = threadIdx.x, slot = lane >> 3, t = lane & 7;
-    const int i = w.i_begin + (int)blockIdx.x * 8 + t;
-    const bool live = i < w.i_end;
-    const int ic = live ? i : w.i_end - 1;
-    const float xi = w.px[ic], yi = w.py[ic], ri = w.radius[ic];
+    const int pos = w.i_begin + (int)blockIdx.x * 8 + t;            // position in walk order; i: the body there
+    const bool live = pos < w.i_end;
+    const int pc = live ? pos : w.i_end - 1;
+    const int i = w.order ? w.order[pc] : pc;
+    const float xi = w.px[i], yi = w.py[i], ri = w.radius[i];
     const float eps = 1e-6f, soft2 = 0.001f * 0.001f;
     const float vote_margin = 4e-6f * w.theta;
     const unsigned long long below_me = (1ull << lane) - 1ull;

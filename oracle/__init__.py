@@ -57,6 +57,9 @@ def lib():
         L.oracle_bh_group_counters.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, _f32p, C.c_float, _i32p, _i32p,
                                                np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]
         L.oracle_bh_steps.argtypes = [C.c_int] + [_f32p] * 6 + [C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
+        L.oracle_path_keys.argtypes = [C.c_int, C.c_float, _f32p, _f32p, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]
+        L.oracle_bh_accel_ordered.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, _f32p, C.c_float, _i32p, _f64p, _f64p, _i64p,
+                                              _i32p, _i32p]
         L.oracle_bh_steps_counted.argtypes = L.oracle_bh_steps.argtypes + [_i64p, _i64p]
         _lib = L
     return _lib
@@ -176,6 +179,16 @@ class Tree:
         lib().oracle_bh_accel(self.h, b.n, b.posX, b.posY, b.radius, theta, int(f64), group_size, ax, ay, cnt)
         return ax, ay, dict(visits=int(cnt[0]), accepts=int(cnt[1]))
 
+    def accel_sorted(self, b, theta, spread, order=None):
+        """bh_sorted walk (no reference counterpart): groups of 8 consecutive bodies in quadrant-path order."""
+        if order is None:
+            order = sorted_order(b, spread)
+        ax = np.zeros(b.n); ay = np.zeros(b.n); cnt = np.zeros(2, np.int64)
+        g = (b.n + 7) // 8
+        gv = np.zeros(g, np.int32); ga = np.zeros(g, np.int32)
+        lib().oracle_bh_accel_ordered(self.h, b.n, b.posX, b.posY, b.radius, theta, order, ax, ay, cnt, gv, ga)
+        return ax, ay, dict(visits=int(cnt[0]), accepts=int(cnt[1]), groups=(gv, ga))
+
     def group_counters(self, b, theta):
         """Per group of 8 bodies: (visits, accepts, hash of the accepted node indices in walk order)."""
         g = b.n // 8
@@ -188,6 +201,13 @@ class Tree:
             lib().oracle_tree_destroy(self.h)
         except Exception:
             pass
+
+
+def sorted_order(b, spread):
+    """Bodies in the order the GPU build lists them: by (quadrant-path key, index); out-of-box bodies last."""
+    keys = np.zeros(b.n, np.uint64)
+    lib().oracle_path_keys(b.n, spread, b.posX, b.posY, keys)
+    return np.argsort(keys, kind="stable").astype(np.int32)
 
 
 def set_main_cpp_flavour(on):

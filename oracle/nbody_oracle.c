@@ -387,7 +387,7 @@ void oracle_tree_stats(const oracle_tree *t, int out[4])
 /* mode f64: same accepted-node set as the f32 vote (the vote is evaluated in float, as    */
 /* the reference does), contributions summed in double.                                   */
 /* ------------------------------------------------------------------------------------ */
-static void bh_group(const oracle_tree *t, int start, int lanes, const float *px, const float *py,
+static void bh_group(const oracle_tree *t, const int *ids, int lanes, const float *px, const float *py,
                      const float *radius, float theta, int use_f64, double *ax, double *ay,
                      long long *visits, long long *accepts, unsigned long long *accept_hash)
 {
@@ -405,7 +405,7 @@ static void bh_group(const oracle_tree *t, int start, int lanes, const float *px
         float width = nd->brX - nd->tlX;                                      /* :251 */
         int all_far = 1;
         for (int k = 0; k < lanes; ++k) {
-            float dx = nd->comX - px[start + k], dy = nd->comY - py[start + k];
+            float dx = nd->comX - px[ids[k]], dy = nd->comY - py[ids[k]];
             float d = sqrtf(fmaf(dx, dx, dy * dy));                           /* :256-257 (contracted) */
             float ratio = width / (d + eps);                                  /* :259-260 */
             if (!(ratio < theta)) all_far = 0;                                /* :262-264 */
@@ -415,19 +415,19 @@ static void bh_group(const oracle_tree *t, int start, int lanes, const float *px
             if (accepts) ++*accepts;
             if (accept_hash) *accept_hash = (*accept_hash ^ (unsigned long long)(unsigned)ni) * 1099511628211ull;
             for (int k = 0; k < lanes; ++k) {                                 /* A6, :176-225 */
-                if ((float)nd->bodyIndex == (float)(start + k)) continue;     /* :197-198 */
+                if ((float)nd->bodyIndex == (float)ids[k]) continue;     /* :197-198 */
                 if (use_f64) {
-                    double dx = (double)nd->comX - px[start + k], dy = (double)nd->comY - py[start + k];
+                    double dx = (double)nd->comX - px[ids[k]], dy = (double)nd->comY - py[ids[k]];
                     double d = sqrt(dx * dx + dy * dy);
-                    double sd = d > (double)radius[start + k] ? d : (double)radius[start + k];
+                    double sd = d > (double)radius[ids[k]] ? d : (double)radius[ids[k]];
                     double f = ((double)G_LOCAL * nd->mass) / (sd * sd + (double)(soft * soft));
                     double inv = 1.0 / (d + (double)eps);
                     accx[k] += dx * inv * f;
                     accy[k] += dy * inv * f;
                 } else {
-                    float dx = nd->comX - px[start + k], dy = nd->comY - py[start + k];
+                    float dx = nd->comX - px[ids[k]], dy = nd->comY - py[ids[k]];
                     float d = sqrtf(fmaf(dx, dx, dy * dy));                   /* :193-194 */
-                    float sd = d > radius[start + k] ? d : radius[start + k]; /* :201-202 */
+                    float sd = d > radius[ids[k]] ? d : radius[ids[k]]; /* :201-202 */
                     float f = (G_LOCAL * nd->mass) / fmaf(sd, sd, soft * soft); /* :203-209 (contracted) */
                     float inv = 1.0f / (d + eps);                             /* :212-213 */
                     faccx[k] += (dx * inv) * f;                               /* :215-225 */
@@ -445,8 +445,8 @@ static void bh_group(const oracle_tree *t, int start, int lanes, const float *px
     }
     free(st);
     for (int k = 0; k < lanes; ++k) {
-        ax[start + k] = use_f64 ? accx[k] : (double)faccx[k];
-        ay[start + k] = use_f64 ? accy[k] : (double)faccy[k];
+        ax[ids[k]] = use_f64 ? accx[k] : (double)faccx[k];
+        ay[ids[k]] = use_f64 ? accy[k] : (double)faccy[k];
     }
 }
 
@@ -459,8 +459,11 @@ void oracle_bh_accel(const oracle_tree *t, int n, const float *px, const float *
     if (group_size < 1 || group_size > VEC_STRIDE) group_size = VEC_STRIDE;
     int lim = n - (n % group_size);
 #pragma omp parallel for schedule(dynamic, 16) reduction(+ : visits, accepts)
-    for (int i = 0; i < lim; i += group_size)
-        bh_group(t, i, group_size, px, py, radius, theta, use_f64, ax, ay, &visits, &accepts, NULL);
+    for (int i = 0; i < lim; i += group_size) {
+        int ids[VEC_STRIDE];
+        for (int k = 0; k < group_size; ++k) ids[k] = i + k;
+        bh_group(t, ids, group_size, px, py, radius, theta, use_f64, ax, ay, &visits, &accepts, NULL);
+    }
     for (int i = lim; i < n; ++i) ax[i] = ay[i] = 0.0;
     if (counters) { counters[0] = visits; counters[1] = accepts; }
 }
@@ -478,12 +481,54 @@ void oracle_bh_group_counters(const oracle_tree *t, int n, const float *px, cons
     for (int i = 0; i < lim; i += VEC_STRIDE) {
         long long v = 0, a = 0;
         unsigned long long h = 0;
-        bh_group(t, i, VEC_STRIDE, px, py, radius, theta, 0, ax, ay, &v, &a, &h);
+        int ids[VEC_STRIDE];
+        for (int k = 0; k < VEC_STRIDE; ++k) ids[k] = i + k;
+        bh_group(t, ids, VEC_STRIDE, px, py, radius, theta, 0, ax, ay, &v, &a, &h);
         grp_visits[i / VEC_STRIDE] = (int)v;
         grp_accepts[i / VEC_STRIDE] = (int)a;
         if (grp_hash) grp_hash[i / VEC_STRIDE] = h;
     }
     free(ax); free(ay);
+}
+
+/* ---- bh_sorted (NO reference counterpart: nbody_config.bh_sorted) ------------------------------ */
+/* Quadrant-path key of every body: the digits TL,TR,BL,BR = 0..3 (:105-108) of its descent through the fixed box with
+ * the reference's comparisons and float midpoints (:83-85, :98-99), 31 levels, 2 bits each; a body outside the box
+ * gets bit 63 | index.  Sorting bodies by (key, index) is the order in which the GPU build lists them. */
+void oracle_path_keys(int n, float spread, const float *px, const float *py, unsigned long long *keys)
+{
+    for (int i = 0; i < n; ++i) {
+        float x = px[i], y = py[i], tlx = -spread, tly = -spread, brx = spread, bry = spread;
+        if (x < tlx || x > brx || y < tly || y > bry) { keys[i] = (1ull << 63) | (unsigned long long)(unsigned)i; continue; }
+        unsigned long long key = 0;
+        for (int l = 0; l < 31; ++l) {
+            float mx = (tlx + brx) / 2.0f, my = (tly + bry) / 2.0f;
+            int qx = x > mx, qy = y > my;
+            key = (key << 2) | (unsigned long long)(qy * 2 + qx);
+            if (qx) tlx = mx; else brx = mx;
+            if (qy) tly = my; else bry = my;
+        }
+        keys[i] = key;
+    }
+}
+
+/* The reference's walk and node kernel (:176-277) over groups of 8 consecutive entries of `order` instead of 8
+ * consecutive body indices; a last, shorter group votes with the lanes it has.  Counters per group position. */
+void oracle_bh_accel_ordered(const oracle_tree *t, int n, const float *px, const float *py, const float *radius,
+                             float theta, const int *order, double *ax, double *ay, long long counters[2],
+                             int *grp_visits, int *grp_accepts)
+{
+    long long visits = 0, accepts = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : visits, accepts)
+    for (int p = 0; p < n; p += VEC_STRIDE) {
+        int lanes = n - p < VEC_STRIDE ? n - p : VEC_STRIDE;
+        long long v = 0, a = 0;
+        bh_group(t, order + p, lanes, px, py, radius, theta, 0, ax, ay, &v, &a, NULL);
+        if (grp_visits) grp_visits[p / VEC_STRIDE] = (int)v;
+        if (grp_accepts) grp_accepts[p / VEC_STRIDE] = (int)a;
+        visits += v; accepts += a;
+    }
+    if (counters) { counters[0] = visits; counters[1] = accepts; }
 }
 
 /* A7: nsteps of build -> walk -> Euler, benchmark.cpp:354-403 (use_parallel == 0: build only, :359) */
