@@ -989,24 +989,23 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
             if (a.z != 0.0f) {                                  // benchmark.cpp:248
                 const float dx = a.x - xi, dy = a.y - yi;       // :254-255
                 const float d2 = __builtin_fmaf(dx, dx, dy * dy);
-                float d, inv;
-                bool far;
-                if constexpr (kFast) {
-                    d = __builtin_amdgcn_sqrtf(d2);
-                    inv = __builtin_amdgcn_rcpf(d + eps);
-                    const float q = a.w * inv;
-                    far = q < w.theta;
-                    if (__any(__builtin_fabsf(q - w.theta) <= vote_margin))          // rare: ~1e-4 of the waves' visits
-                        far = (a.w / (__builtin_sqrtf(d2) + eps)) < w.theta;
-                } else {
-                    d = __builtin_sqrtf(d2);                                         // :256-257
-                    far = (a.w / (d + eps)) < w.theta;                               // :259-262
-                }
+                // The vote is a boolean, so both modes take it with the hardware's 1-ulp sqrt/rcp (3 instructions instead
+                // of the ~30 of a correctly rounded sqrt and division) unless the ratio is within 4e-6 (relative, > 10x
+                // its error bound) of theta; then the wave redoes the node with the IEEE expressions of
+                // benchmark.cpp:256-262.  Same decisions as the oracle either way (the counters are compared).
+                float d = __builtin_amdgcn_sqrtf(d2);
+                float inv = __builtin_amdgcn_rcpf(d + eps);
+                const float q = a.w * inv;
+                bool far = q < w.theta;
+                if (__any(__builtin_fabsf(q - w.theta) <= vote_margin))              // rare: ~1e-4 of the waves' visits
+                    far = (a.w / (__builtin_sqrtf(d2) + eps)) < w.theta;
                 const unsigned long long fm = __ballot(far || !live);
                 const bool all_far = ((fm >> grp_shift) & 0xFFull) == 0xFFull;
                 if (b.x < 0 || all_far) {                       // :266 leaf or every lane far
                     ++accepts;
-                    // computeForce_kernel, benchmark.cpp:188-225
+                    // computeForce_kernel, benchmark.cpp:188-225: the accepted term is computed in IEEE arithmetic
+                    // (correctly rounded sqrt and divisions) unless bh_fast_math asked for the hardware's
+                    if constexpr (!kFast) d = __builtin_sqrtf(d2);                  // :193-194
                     const float sd = __builtin_fmaxf(d, ri);    // clamp radius is the TARGET's only (:201-202)
                     float f;
                     if constexpr (kFast) {
