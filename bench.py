@@ -79,20 +79,29 @@ class ClockSampler:
             self.th.start()
         return self
 
-    def stop(self, t0, t1):
+    def stop(self, t0, t1, linger_s=0.0):
         """Summary of the refreshes first seen inside [t0, t1] (perf_counter times; the GPU was under this load
         without a break from t0 on)."""
+        if linger_s > 0 and self.th and not [r for r in self.rows if t0 + 1.0 <= r[0] <= t1]:
+            time.sleep(linger_s)                              # short run: wait for the refresh that covers its end
         self._stop = True
         if self.th:
             self.th.join(timeout=2.0)
         # a refresh describes the second BEFORE it (its average_gfx_activity says how much of that second was busy):
         # keep the ones whose whole second lay under the load
         rows = [r for r in self.rows if t0 + 1.0 <= r[0] <= t1 and r[2] == r[2] and not (r[4] < 99.0)]
+        partial = False
         if not rows:
-            return {"gfx_mhz": None, "note": self.err or "no gpu_metrics refresh covers a fully loaded second (it refreshes once per second): run more steps"}
+            # a run shorter than two refreshes: take the refresh with the highest clock seen under the load (its second
+            # was only partly loaded, so the figure is a lower bound) and say so
+            cand = [r for r in self.rows if t0 <= r[0] <= t1 + 1.05 and r[2] == r[2] and r[2] > 1000.0]
+            if cand:
+                rows, partial = [max(cand, key=lambda r: r[2])], True
+        if not rows:
+            return {"gfx_mhz": None, "note": self.err or "no gpu_metrics refresh under the load (it refreshes once per second): run more steps"}
         clk = np.array([r[2] for r in rows]); pw = np.array([r[3] for r in rows])
         out = {"gfx_mhz": float(np.median(clk)), "gfx_mhz_min": float(clk.min()), "gfx_mhz_max": float(clk.max()),
-               "snapshots": len(rows),
+               "snapshots": len(rows), "partial_second": partial,
                "source": "amdsmi gpu_metrics current_gfxclks, mean over the XCDs; one snapshot per 1-s refresh, kept when its whole second was under this load (gfx activity >= 99 %)"}
         if np.isfinite(pw).any():
             out["socket_power_w"] = float(np.nanmedian(pw))
@@ -239,7 +248,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    clock = sampler.stop(t_load, t1) if sampler else None
+    clock = sampler.stop(t_load, t1, linger_s=1.05) if sampler else None
     if bh:
         sim.upload_state(*bodies[1:5])
         sim.sim.profile(True).profile_reset()
