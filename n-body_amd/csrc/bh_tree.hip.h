@@ -71,8 +71,10 @@ struct BhCounters {          // device-resident scalars of one build/walk
 #ifdef NBODY_WIDE_TIMING
     unsigned long long dbg[24];  // developer build: 100 MHz ticks at phase boundaries of the one-workgroup kernels
 #endif
-    int valid_acc;           // small-N build: in-box bodies counted by bh_keys_kernel (one atomic per wave); moved into
-                             // `valid` and zeroed by bh_prep_small_kernel
+    int max_depth;           // deepest internal cell of this build (wave-reduced atomicMax in bh_nodes_kernel); published to
+                             // the host as the hint for how many centre-of-mass launches the NEXT build needs
+    int valid_part[64];      // small-N build: in-box bodies counted by bh_keys_kernel (one atomic per wave, spread over 64
+                             // counters), summed by bh_prep_small_kernel, zeroed by bh_nodes_kernel for the next build
 };
 
 // walk record of a node: A = {comX, comY, mass, width}, B = {childBase (-1: leaf), bodyIndex (-1: none)}
@@ -136,16 +138,26 @@ __global__ __launch_bounds__(kBhBlock) void bh_keys_kernel(const float* __restri
         vals[i] = i;
         tie[i] = (uint16_t)(tx | (ty << 8));
     }
-    // small-N build (count_valid): number of in-box bodies = where the invalid keys start after the sort; one atomic
-    // per wave (a few hundred in all — at 10^6 bodies the 15 625 same-address atomics would cost more than the
-    // binary search of bh_valid_kernel, which the large build keeps)
+    // small-N build (count_valid): number of in-box bodies = where the invalid keys start after the sort, one atomic
+    // per wave.  Measured: same-line device-scope atomics cost ~4 ns each and a short kernel cannot end before they
+    // are all acknowledged — 15 625 of them turn this 20-us kernel into a 79-us one at N = 10^6, so the large build
+    // keeps its one-thread binary search (bh_valid_kernel, ~5 us).
     if (count_valid) {
         const unsigned long long in_mask = __ballot(inside);
-        if ((threadIdx.x & 63) == 0 && in_mask) atomicAdd(&ctr->valid_acc, __popcll(in_mask));
+        if ((threadIdx.x & 63) == 0 && in_mask)
+            atomicAdd(&ctr->valid_part[(blockIdx.x * (kBhBlock / 64) + (threadIdx.x >> 6)) & 63], __popcll(in_mask));
     }
 }
 
-// number of valid (in-box) bodies = first sorted index with the invalid bit set
+__device__ __forceinline__ int bh_valid_total(const BhCounters* __restrict__ ctr)
+{
+    int m = 0;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) m += ctr->valid_part[k];
+    return m;
+}
+
+// large build: number of valid (in-box) bodies = first sorted index with the invalid bit set
 __global__ void bh_valid_kernel(const uint64_t* __restrict__ keys, int n, BhCounters* __restrict__ ctr)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -168,6 +180,7 @@ __device__ __forceinline__ void bh_reset_counters(BhCounters* __restrict__ ctr, 
     ctr->visits = 0;
     ctr->accepts = 0;
     ctr->wave_iters = 0;
+    ctr->max_depth = 0;
 }
 
 __global__ void bh_reset_kernel(BhCounters* __restrict__ ctr, float root_half0)
@@ -498,7 +511,7 @@ __global__ __launch_bounds__(kBhFixBlock) void bh_prep_small_kernel(const uint64
     __shared__ int part[kBhFixBlock / 64];
     const int tid = threadIdx.x;
     BH_DBG_TICK(ctr, 0);
-    const int M0 = ctr->valid_acc;                                 // counted by bh_keys_kernel; zeroed below for the next build
+    const int M0 = bh_valid_total(ctr);                            // counted by bh_keys_kernel
     // 2b. second instances of bodies on split lines.  All but a few bodies per million have no tie on their path:
     // the two dependent loads that say so (body of the sorted slot, its tie record) are issued eight at a time.
     constexpr int kBatch = 16;
@@ -513,7 +526,7 @@ __global__ __launch_bounds__(kBhFixBlock) void bh_prep_small_kernel(const uint64
             if (first[u] != kBhLevels) bh_ties_one(i0 + u * kBhFixBlock, M0, keys, vals, px, py, tie, ctr, T);
     }
     __syncthreads();            // one workgroup = one CU = one L1: a barrier is all the ordering the phases need
-    if (tid == 0) { ctr->valid = M0; ctr->valid_acc = 0; }
+    if (tid == 0) ctr->valid = M0;
     BH_DBG_TICK(ctr, 1);
     bh_tie_fixpoint_body(keys, vals, px, py, tie, ctr, T);
     BH_DBG_TICK(ctr, 2);
@@ -616,7 +629,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
                                                             const float* __restrict__ py, BhTree t,
                                                             BhCounters* __restrict__ ctr, int* __restrict__ overflow_host,
                                                             const uint64_t* __restrict__ keys_unmerged,
-                                                            const int* __restrict__ vals_unmerged)
+                                                            const int* __restrict__ vals_unmerged, int track_depth)
 {
     // small-N build: without second instances the merged arrays were never written, they ARE the sorted primaries
     if (keys_unmerged != nullptr && ctr->ghosts == 0) { keys = keys_unmerged; vals = vals_unmerged; }
@@ -631,6 +644,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
         // buffer's overflow, 2, was set by the kernels before this one)
         overflow_host[0] = I > t.cap_internal ? 1 : ctr->overflow;
         overflow_host[1] = I < t.cap_internal ? I : t.cap_internal;     // hint for the NEXT build's choice of COM pass
+        for (int k = 0; k < 64; ++k) ctr->valid_part[k] = 0;            // everybody has read ctr->valid by now
         if (M < 2) {                                           // degenerate trees: root is a leaf / empty
             const int b = M == 1 ? vals[0] : -1;
             t.A[0] = make_float4(b >= 0 ? px[b] : 0.0f, b >= 0 ? py[b] : 0.0f, b >= 0 ? m[b] : 0.0f, 2.0f * spread);
@@ -660,6 +674,15 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
         t.self[0] = 0;
     }
     t.depth[c] = (uint8_t)d;
+    if (track_depth) {
+        // deepest cell of the build, for the next build's choice of centre-of-mass launches: one atomicMax per wave
+        // (live lanes only reach this point).  Only for trees of up to ~200 000 cells: 11 000 same-address atomics
+        // cost 0.08 ms at N = 10^6, more than the launches the hint saves there.
+        int dm = d;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dm = max(dm, __shfl_xor(dm, o, 64));
+        if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(true))) atomicMax(&ctr->max_depth, dm);
+    }
 
     // body range [i, e) of the cell and its quadrant boundaries
     const int e = d ? bh_gallop_lower_bound(keys, i + 1, M, (prefix + 1) << shift) : M;
@@ -781,6 +804,23 @@ __global__ __launch_bounds__(kBhBlock) void bh_com_kernel(BhTree t, const BhCoun
         if (((x >> (8 * k)) & 0xFFu) == 0 && c4 + k < I) bh_com_cell(t, c4 + k);
 }
 
+// The per-depth launches cover depths below `top`, chosen by the host from the deepest cell of the PREVIOUS build (+2).
+// This one launch, enqueued before them, is the safety net for a tree that has grown deeper since: one workgroup,
+// level loop over every depth >= top — nothing to do (one load) in the expected case, slow but correct otherwise.
+// It also publishes this build's deepest cell to the host-mapped hint word for the next build.
+__global__ __launch_bounds__(1024) void bh_com_deep_kernel(BhTree t, const BhCounters* __restrict__ ctr, int top, int* __restrict__ hint_host)
+{
+    const int md = ctr->max_depth;                 // 0 when the node kernel does not track it: then top is 31 and
+    if (threadIdx.x == 0) hint_host[2] = md;       // this kernel has nothing to cover
+    if (md < top) return;
+    const int I = ctr->internal;
+    for (int d = md; d >= top; --d) {
+        for (int c = threadIdx.x; c < I; c += 1024)
+            if (t.depth[c] == d) bh_com_cell(t, c);
+        __syncthreads();
+    }
+}
+
 // Small trees: all depths in ONE launch of one workgroup (31 launches of a few microseconds each are most of a
 // Barnes-Hut step at N = 10 000).
 //
@@ -803,10 +843,12 @@ __device__ __forceinline__ bool bh_com_next(const int* lstart, const int* lend, 
     return d >= 0;
 }
 
-__global__ __launch_bounds__(kBhComBlock) void bh_com_small_kernel(BhTree t, const BhCounters* __restrict__ ctr, int max_internal)
+__global__ __launch_bounds__(kBhComBlock) void bh_com_small_kernel(BhTree t, const BhCounters* __restrict__ ctr, int max_internal,
+                                                                   int* __restrict__ hint_host)
 {
     const int I = ctr->internal;
     (void)max_internal;
+    if (threadIdx.x == 0 && hint_host) hint_host[2] = ctr->max_depth;
     __shared__ __align__(16) unsigned char lds[14 * kBhComLds];    // LDS path: x, y, mass, order; level loop: depths
     __shared__ int lstart[kBhLevels + 1], lend[kBhLevels + 1];
     const int tid = threadIdx.x;

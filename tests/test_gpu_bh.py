@@ -235,6 +235,50 @@ def test_wide_walk_equals_the_group_per_8_lanes_walk(nb, O, n, theta, fast, monk
         assert np.array_equal(ax1, ox.astype(np.float32)) and np.array_equal(ay1, oy.astype(np.float32))
 
 
+def test_tree_that_outgrows_the_previous_builds_depth_hint(nb, O):
+    """The per-depth centre-of-mass launches cover the depths the PREVIOUS build needed (+2; the node kernel leaves its
+    deepest cell in host-mapped memory), one safety-net launch covers everything deeper.  First build: a shallow tree
+    (a jittered lattice, depth ~9).  Then the same context gets a state with two bodies 2e-5 apart (depth ~26): the
+    stale hint must cost time, not results — tree and accelerations equal the oracle's, and so does the build after
+    it, which has the fresh hint."""
+    n = 40000                                                      # > 11 264 cells: the per-depth pass
+    rng = np.random.default_rng(12)
+    side = 200
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+    b = O.init_disc(n, seed=1)
+    b.posX[:] = ((gx.ravel()[:n] - side / 2) * 3.9 + rng.uniform(-0.5, 0.5, n)).astype(np.float32)
+    b.posY[:] = ((gy.ravel()[:n] - side / 2) * 3.9 + rng.uniform(-0.5, 0.5, n)).astype(np.float32)
+    deep = b.copy()
+    deep.posX[17], deep.posY[17] = np.float32(1.0), np.float32(1.0)          # near the origin, where 2e-5 is many ulps
+    deep.posX[4000], deep.posY[4000] = np.float32(1.0) + np.float32(2e-5), np.float32(1.0)
+    with nb.NBodySim(n, useBarnesHut=True) as sim:
+        sim.upload(*b.arrays())
+        sim.compute_accel().sync()
+        shallow = sim.bh_tree()
+        assert np.array_equal(canonical(shallow), canonical(O.Tree(n).build(b, 400.0).pool()))
+        sim.upload_state(deep.posX, deep.posY, deep.velX, deep.velY)
+        ot = O.Tree(n).build(deep, 400.0)
+        assert ot.stats()["depth"] >= ot_depth_of(shallow) + 8
+        for _ in range(2):                                         # stale hint, then fresh hint
+            sim.compute_accel().sync()
+            ax, ay = sim.accel()
+            tree = sim.bh_tree()
+            assert np.array_equal(canonical(tree), canonical(ot.pool()))
+            ox, oy, ocnt = ot.accel(deep, 1.0)
+            assert sim.bh_counters() == ocnt
+            assert np.array_equal(ax, ox.astype(np.float32)) and np.array_equal(ay, oy.astype(np.float32))
+
+
+def ot_depth_of(pool):
+    depth, stack = 0, [(0, 0)]
+    while stack:
+        ni, d = stack.pop()
+        depth = max(depth, d)
+        if pool[ni]["children"][0] != -1:
+            stack.extend((int(c), d + 1) for c in pool[ni]["children"])
+    return depth
+
+
 @pytest.mark.parametrize("n", [1, 7, 8, 9, 16, 65, 1000])
 def test_ragged_sizes(nb, O, n):
     b = O.init_disc(n, seed=100 + n)

@@ -38,6 +38,40 @@ def test_one_rank_communicator_steps_like_a_plain_context(nb, O, bh):
         assert np.array_equal(got[k], want[k]), k
 
 
+def test_sharded_driver_native_exchange_one_rank(nb, O):
+    """ShardedSim(exchange="native") — what `NBODY_EXCHANGE=native bench.py` runs: the RCCL id travels through
+    torch.distributed, the all-gather is the library's own ncclAllGather on the shared stream."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from nbody_amd.sharded import ShardedSim
+    n = 8192
+    b = O.init_disc(n, seed=6)
+    with nb.NBodySim(n) as ref:
+        ref.upload(*b.arrays()); ref.step(2)
+        want = ref.download()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sim = ShardedSim(nb, n, 0, 1, device=0, dist=dist, exchange="native")
+        assert sim.exchange_mode == "native"
+        sim.upload(*b.arrays())
+        sim.sim.comm_init(0, 1, nb.comm_unique_id())               # world = 1: ShardedSim skips it, do it here
+        sim.step(2)
+        sim.exchange(force=True)
+        sim.sync()
+        got = sim.sim.download()
+        sim.close()
+    finally:
+        dist.destroy_process_group()
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+
+
 def test_comm_init_checks_the_shard_plan(nb, O):
     n = 4096
     uid = nb.comm_unique_id()

@@ -335,7 +335,33 @@ def test_profile_counters(nb, O):
         sim.step(5)
         ms, cnt = sim.profile_read(0)
         ms_i, cnt_i = sim.profile_read(1)
+        per_launch = sim.profile_samples(0)                      # nbody_profile_samples: every launch's duration
+        assert len(per_launch) == 5 and np.all(per_launch > 0) and np.isclose(per_launch.sum(), ms, rtol=1e-5)
+        sim.profile_reset()
+        assert len(sim.profile_samples(0)) == 0
     assert cnt == 5 and cnt_i == 5 and ms > 0 and ms_i > 0
+
+
+@pytest.mark.parametrize("bh", [False, True])
+def test_upload_state_equals_a_fresh_upload(nb, O, bh):
+    """nbody_upload_state: new positions/velocities for the bodies already uploaded (no scan of m/radius, no rebuild of
+    the clamp constants); stepping from it equals stepping from a full nbody_upload of the same state."""
+    b = O.init_disc(4096, seed=3)
+    c = O.init_disc(4096, seed=4)                                # another state of the same bodies (same m, radius)
+    with nb.NBodySim(b.n, useBarnesHut=bh) as fresh:
+        fresh.upload(*c.arrays()); fresh.step(2)
+        want = fresh.download()
+    with nb.NBodySim(b.n, useBarnesHut=bh) as sim:
+        with pytest.raises(nb.NBodyError):
+            sim.upload_state(c.posX, c.posY, c.velX, c.velY)     # nothing uploaded yet
+        sim.upload(*b.arrays()); sim.step(3)
+        sim.upload_state(c.posX, c.posY, c.velX, c.velY); sim.step(2)
+        got = sim.download()
+        bad = c.posX.copy(); bad[7] = np.inf
+        with pytest.raises(nb.NBodyError):
+            sim.upload_state(bad, c.posY, c.velX, c.velY)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
 
 
 def test_sharded_driver_torch_plumbing(nb, O):
