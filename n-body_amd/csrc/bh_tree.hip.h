@@ -1126,8 +1126,9 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
 // visit/accept counters are bit-identical to it and to the oracle.  The lists live in LDS and are bounded; when a
 // traversal outgrows them it is abandoned and its root is split into its four children, each walked on its own, in
 // DFS order (a node whose lists overflow was opened, so this is exactly what the reference does with it).
-constexpr int kWideStack = 512;      // pending nodes
-constexpr int kWideAccepts = 1024;   // accepted nodes of one traversal
+// LDS list capacities are template parameters (accepted nodes of one traversal, pending nodes): 1024/512 when the
+// launch is a single round anyway (19.5 KB, 2 waves per SIMD), 512/256 (10.5 KB and <= 128 VGPRs: 4 waves per SIMD)
+// when there are more groups than that holds.
 constexpr int kWidePerSlot = 4;      // nodes tested per slot per iteration of pass 1
 constexpr int kWideRound = 2;        // nodes per slot per round of pass 2
 
@@ -1184,16 +1185,17 @@ __device__ __noinline__ void bh_wide_sort(unsigned long long* __restrict__ akey,
     for (int r = 0; r < R; ++r) anode[lane * R + r] = v[r];
 }
 
-template <bool kFast>
+template <bool kFast, int kAcc, int kStk>
 __global__ __launch_bounds__(64) void bh_walk_wide_kernel(const BhWalkArgs w)
 {
 #pragma clang fp contract(off)
-    __shared__ unsigned long long pkey[kWideStack];
-    __shared__ int pnode[kWideStack];
-    __shared__ unsigned long long akey[kWideAccepts];
-    __shared__ int anode[kWideAccepts];
+    __shared__ unsigned long long pkey[kStk];
+    __shared__ int pnode[kStk];
+    __shared__ unsigned long long akey[kAcc];
+    __shared__ int anode[kAcc];
     __shared__ float termx[8 * kWideRound][8], termy[8 * kWideRound][8];
     __shared__ int tasks[128];
+    __shared__ unsigned char tdepth[128];
     const int lane = threadIdx.x, slot = lane >> 3, t = lane & 7;
     const int pos = w.i_begin + (int)blockIdx.x * 8 + t;            // position in walk order; i: the body there
     const bool live = pos < w.i_end;
@@ -1213,11 +1215,22 @@ __global__ __launch_bounds__(64) void bh_walk_wide_kernel(const BhWalkArgs w)
 #else
 #define WIDE_TICK(acc) do { } while (0)
 #endif
+    // How many levels to split up front: the group's accept count of the PREVIOUS walk (still in grp_accepts) says
+    // whether the whole tree fits the accept list; if not, starting with the root's children (grandchildren, ...) as
+    // separate traversals saves the abandoned attempt.  A hint only: a wrong one costs time, the overflow path below
+    // splits whatever still does not fit.
+    int presplit = 0;
+    {
+        const int hint = w.grp_accepts[(w.i_begin >> 3) + blockIdx.x];
+        for (int h = hint; h > kAcc - kAcc / 4 && presplit < 4; h >>= 2) ++presplit;
+    }
     int ntask = 1;
-    if (lane == 0) tasks[0] = 0;
+    if (lane == 0) { tasks[0] = 0; tdepth[0] = 0; }
     __syncthreads();
     while (ntask > 0) {
         const int root = tasks[--ntask];
+        const int rdepth = tdepth[ntask];
+        bool first_iter = true;
         // ---- pass 1: which nodes does the reference accept below `root`? ----
         int sp = 1, na = 0;
         unsigned tv = 0;
@@ -1264,27 +1277,28 @@ __global__ __launch_bounds__(64) void bh_walk_wide_kernel(const BhWalkArgs w)
                 const bool open = massive && !accept;
                 const unsigned long long am = __ballot(accept && t == 0);
                 const int apos = na + __popcll(am & below_me);
-                if (accept && t == 0 && apos < kWideAccepts) {
+                if (accept && t == 0 && apos < kAcc) {
                     akey[apos] = key[u] << (__builtin_clzll(key[u]) - 1);      // left-aligned: sentinel at bit 62
                     anode[apos] = node[u];
                 }
                 na += __popcll(am);
                 const unsigned long long om = __ballot(open && t == 0);
                 const int base = sp + 4 * __popcll(om & below_slot);
-                if (open && t < 4 && base + t < kWideStack) {
+                if (open && t < 4 && base + t < kStk) {
                     pnode[base + t] = b[u].x + t;                              // children 0..3 (:272-274)
                     pkey[base + t] = (key[u] << 2) | (unsigned long long)(3 - t);   // popped 3 first (:244)
                 }
                 sp += 4 * __popcll(om);
             }
-            overflow = sp > kWideStack || na > kWideAccepts;
+            overflow = sp > kStk || na > kAcc || (first_iter && rdepth < presplit && sp > 0);
+            first_iter = false;
             __syncthreads();
         }
         if (overflow) {
             // `root` was opened (its lists grew): count its visit and walk its four children one by one, 3 first
             visits += 1;
             const int cb = w.B[root].x;
-            if (lane < 4) tasks[ntask + lane] = cb + lane;
+            if (lane < 4) { tasks[ntask + lane] = cb + lane; tdepth[ntask + lane] = (unsigned char)(rdepth + 1); }
             ntask += 4;
             __syncthreads();
             continue;
@@ -1298,13 +1312,11 @@ __global__ __launch_bounds__(64) void bh_walk_wide_kernel(const BhWalkArgs w)
             while (P < na) P <<= 1;
             for (int e = na + lane; e < P; e += 64) akey[e] = ~0ull;
             __syncthreads();
-            switch (P) {
-                case 64:  bh_wide_sort<1>(akey, anode, lane); break;
-                case 128: bh_wide_sort<2>(akey, anode, lane); break;
-                case 256: bh_wide_sort<4>(akey, anode, lane); break;
-                case 512: bh_wide_sort<8>(akey, anode, lane); break;
-                default:  bh_wide_sort<16>(akey, anode, lane); break;
-            }
+            if (P <= 64) bh_wide_sort<1>(akey, anode, lane);
+            else if (P <= 128) bh_wide_sort<2>(akey, anode, lane);
+            else if (P <= 256) bh_wide_sort<4>(akey, anode, lane);
+            else if (kAcc <= 512 || P <= 512) bh_wide_sort<8>(akey, anode, lane);
+            else if constexpr (kAcc > 512) bh_wide_sort<16>(akey, anode, lane);
             __syncthreads();
         }
         WIDE_TICK(tk2);

@@ -371,8 +371,17 @@ int enqueue_bh_walk(nbody_ctx* ctx, int advance)
     if (const char* e = std::getenv("NBODY_BH_WIDE")) wide = e[0] == '1';       // developer A/B switch
     if (wide) {
         w.lanes_used = 8;
-        if (ctx->cfg.bh_fast_math) bh_walk_wide_kernel<true><<<dim3(groups), dim3(64), 0, ctx->stream>>>(w);
-        else                       bh_walk_wide_kernel<false><<<dim3(groups), dim3(64), 0, ctx->stream>>>(w);
+        // measured (tools/bh_steady.py, walk us at N = 10 000 / 20 000 / 32 768): big lists 101 / 183 / 217, small lists
+        // 97 / 160 / 236 — more resident waves help until the 512-entry accept list starts to overflow
+        bool small_lists = groups <= 3072;
+        if (const char* e = std::getenv("NBODY_BH_WIDE_LISTS")) small_lists = e[0] == 's';     // developer A/B switch
+        if (small_lists) {
+            if (ctx->cfg.bh_fast_math) bh_walk_wide_kernel<true, 512, 256><<<dim3(groups), dim3(64), 0, ctx->stream>>>(w);
+            else                       bh_walk_wide_kernel<false, 512, 256><<<dim3(groups), dim3(64), 0, ctx->stream>>>(w);
+        } else {
+            if (ctx->cfg.bh_fast_math) bh_walk_wide_kernel<true, 1024, 512><<<dim3(groups), dim3(64), 0, ctx->stream>>>(w);
+            else                       bh_walk_wide_kernel<false, 1024, 512><<<dim3(groups), dim3(64), 0, ctx->stream>>>(w);
+        }
     } else {
         w.lanes_used = 8 * bh_walk_groups_per_wave(nt);
         const int per_block = (kBhBlock / 64) * w.lanes_used;      // targets per workgroup
