@@ -94,9 +94,11 @@ class ClockSampler:
         if not rows:
             # a run shorter than two refreshes: take the refresh with the highest clock seen under the load (its second
             # was only partly loaded, so the figure is a lower bound) and say so
-            cand = [r for r in self.rows if t0 <= r[0] <= t1 + 1.05 and r[2] == r[2] and r[2] > 1000.0]
+            # (the refresh with the highest socket POWER, not the highest clock: the moment the load ends the chip jumps
+            # to its 2.4 GHz boost at idle power, which says nothing about the run)
+            cand = [r for r in self.rows if t0 <= r[0] <= t1 + 1.05 and r[2] == r[2] and r[2] > 1000.0 and r[3] == r[3] and r[4] >= 30.0]
             if cand:
-                rows, partial = [max(cand, key=lambda r: r[2])], True
+                rows, partial = [max(cand, key=lambda r: r[3])], True
         if not rows:
             return {"gfx_mhz": None, "note": self.err or "no gpu_metrics refresh under the load (it refreshes once per second): run more steps"}
         clk = np.array([r[2] for r in rows]); pw = np.array([r[3] for r in rows])
@@ -299,7 +301,7 @@ def main():
         # The peak assumes 2.4 GHz; the chip holds less at its power cap.  frac_at_clock prices the same launch
         # against the peak AT THE CLOCK IT RAN AT, which separates "slow box" from "slow kernel".
         mhz = clock.get("gfx_mhz") if clock else None
-        frac_at_clock = achieved / (PEAK_FP32_TFLOPS * mhz / 2400.0) if mhz else None
+        frac_at_clock = achieved / (PEAK_FP32_TFLOPS * mhz / 2400.0) if mhz and not clock.get("partial_second") else None
         line = {
             "metric": "G body-body interactions/s, N=1M naive step",
             "value": value, "unit": "G interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
