@@ -172,8 +172,8 @@ def cpu_baseline_bh(n, theta):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=8)      # 11 steps of 0.18 s: two seconds under load, so that at least one
+    ap.add_argument("--warmup", type=int, default=3)     # 1-s gpu_metrics refresh describes a fully loaded second
     ap.add_argument("--bodies", "--n", dest="n", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["naive", "bh"], default="naive",
