@@ -22,6 +22,10 @@
 //   5. bh_com_kernel       bottom-up, one launch per depth: mass = ((0+m0)+m1)+m2)+m3,
 //                          com = sum(com_k*m_k)/mass in child order (benchmark.cpp:122-141)
 //
+// Up to 32 768 bodies (the reference's default is 10 000) steps 2b-4a are one launch of one workgroup
+// (bh_prep_small_kernel), step 5 runs out of LDS (bh_com_small_kernel) and the walk takes one wave per group
+// (bh_walk_wide_kernel); the separate full-width kernels serve larger trees.
+//
 // Everything is deterministic (no atomics decide any index) and nothing synchronises with the host.
 // Node order is Morton order, not the reference's insertion order; topology, boxes, body indices, masses
 // and centres of mass are identical to oracle_tree_build() (tests compare them by traversal).
@@ -534,7 +538,6 @@ __global__ __launch_bounds__(kBhFixBlock) void bh_prep_small_kernel(const uint64
     const int gmax = T.gcap < kBhSmallGhosts ? T.gcap : kBhSmallGhosts;
     const int G = ghosts < gmax ? ghosts : gmax;
     const uint64_t* mk = keys;                                     // the merged arrays ARE the sorted primaries ...
-    const int* mv = vals;
     if (G > 0) {                                                   // ... unless there are second instances (rare):
         __syncthreads();                                           // sort them by key, bitonic, in LDS, and merge
         int P = 2;
@@ -558,9 +561,7 @@ __global__ __launch_bounds__(kBhFixBlock) void bh_prep_small_kernel(const uint64
         for (int t = tid; t < n + G; t += kBhFixBlock) bh_merge_one(t, keys, vals, n, gkeys_sorted, gvals_sorted, G, okeys, ovals);
         __syncthreads();
         mk = okeys;
-        mv = ovals;
     }
-    (void)mv;
     const int M = M0 + G;
     BH_DBG_TICK(ctr, 3);
     if (tid == 0) ctr->valid = M;
@@ -843,11 +844,10 @@ __device__ __forceinline__ bool bh_com_next(const int* lstart, const int* lend, 
     return d >= 0;
 }
 
-__global__ __launch_bounds__(kBhComBlock) void bh_com_small_kernel(BhTree t, const BhCounters* __restrict__ ctr, int max_internal,
+__global__ __launch_bounds__(kBhComBlock) void bh_com_small_kernel(BhTree t, const BhCounters* __restrict__ ctr,
                                                                    int* __restrict__ hint_host)
 {
     const int I = ctr->internal;
-    (void)max_internal;
     if (threadIdx.x == 0 && hint_host) hint_host[2] = ctr->max_depth;
     __shared__ __align__(16) unsigned char lds[14 * kBhComLds];    // LDS path: x, y, mass, order; level loop: depths
     __shared__ int lstart[kBhLevels + 1], lend[kBhLevels + 1];
@@ -1142,7 +1142,6 @@ __device__ __forceinline__ void bh_wide_sort_regs(unsigned long long (&k)[R], in
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if ((r & J) == 0) {
-                constexpr int dummy = 0; (void)dummy;
                 const int q = r | J;
                 const bool up = ((lane * R + r) & kk) == 0;
                 const bool sw = (k[r] > k[q]) == up;

@@ -314,7 +314,7 @@ int enqueue_bh_build(nbody_ctx* ctx)
     // is no previous build).  A captured graph keeps its choice until the hint crosses the threshold.
     b.com_lds_pass = choose_com_pass(ctx);
     if (b.com_lds_pass) {
-        bh_com_small_kernel<<<1, kBhComBlock, 0, s>>>(b.tree, b.ctr, 0, b.overflow_dev);
+        bh_com_small_kernel<<<1, kBhComBlock, 0, s>>>(b.tree, b.ctr, b.overflow_dev);
     } else {
         // one launch per depth below `top` (the previous build's deepest cell + 2), one safety-net launch for
         // everything at or above it: 31 launches -> ~20 at N = 65 536, ~25 at N = 10^6
