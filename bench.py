@@ -335,8 +335,8 @@ def main():
         if world == 1 and n == 1 << 20 and info["j_slices"] == 8:
             # HBM bytes per force launch from the committed PMC passes of this very command (FETCH_SIZE KiB x2 on
             # gfx950 + WRITE_SIZE KiB); counters cannot be read from inside the process, so this is not live
-            line["roofline"]["traffic"] = (2 * 33041.7 + 65536.0) * 1024
-            line["roofline"]["traffic_source"] = "profiles/r1_naive_n1m_pmc_summary.csv (bytes per launch; algorithmic: 8.4 MB read + 67.1 MB of j-slice partials written)"
+            line["roofline"]["traffic"] = (2 * 32807.1 + 65536.0) * 1024
+            line["roofline"]["traffic_source"] = "profiles/r2_naive_n1m_pmc_summary.csv (bytes per launch; algorithmic: 8.4 MB read + 67.1 MB of j-slice partials written)"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
