@@ -95,16 +95,16 @@ def test_vote_equals_the_compiled_reference_group_by_group(nb, O, name):
     assert cnt["visits"] == int(g["step_visits"][0]) and cnt["accepts"] == int(g["step_accepts"][0])
 
 
-def test_vote_of_the_reference_on_this_host(nb, O):
+@pytest.mark.parametrize("n,theta", [(65536, 1.0), (1_000_000, 1.0), (1_000_000, 0.5)])
+def test_vote_of_the_reference_on_this_host(nb, O, n, theta):
     """The reference's vote goes through vrcpps, whose bits are CPU-vendor specific: the goldens were
-    made on the build container's Intel host.  This runs the compiled reference on THIS box's host CPU, N = 65 536,
-    theta = 1, and compares its per-group counters with the GPU walk's."""
+    made on the build container's Intel host.  This runs the compiled reference on THIS box's host CPU (N = 65 536,
+    and BASELINE config 4's full N = 10^6 at both thetas) and compares its per-group counters with the GPU walk's."""
     if not O.ref_available():
         pytest.skip("oracle/_ref/libnbody_ref.so not built")
-    n = 65536
     b = O.init_disc(n, seed=777)
-    r = O.ref_run(n, use_barnes_hut=1, nsteps=1, bodies=b, theta=1.0)
-    _, _, _, _, cnt = gpu_bh(nb, b, want_groups=True)
+    r = O.ref_run(n, use_barnes_hut=1, nsteps=1, bodies=b, theta=theta)
+    _, _, _, _, cnt = gpu_bh(nb, b, theta=theta, want_groups=True)
     v, a = cnt["groups"]
     differ = int(((v != r["grp_visits"]) | (a != r["grp_accepts"])).sum())
     print(f"[vote census on this host] {differ} of {n // 8} groups differ; reference {int(r['step_visits'][0])} visits, "
