@@ -19,14 +19,15 @@
 //   4. bh_nodes_kernel     one thread per internal cell c: binary-search the three quadrant boundaries of
 //                          its body range, emit its four children at node indices 1+4c .. 4+4c (leaf with
 //                          its body / empty leaf / internal child with childBase = 1 + 4*id(child))
-//   5. bh_com_kernel       bottom-up, one launch per depth: mass = ((0+m0)+m1)+m2)+m3,
+//   5. bh_com_climb_kernel bottom-up in one launch (the last child to finish evaluates the parent); above 2^21 bodies
+//                          bh_com_kernel, one launch per depth: mass = ((0+m0)+m1)+m2)+m3,
 //                          com = sum(com_k*m_k)/mass in child order (benchmark.cpp:122-141)
 //
 // Up to 32 768 bodies (the reference's default is 10 000) steps 2b-4a are one launch of one workgroup
-// (bh_prep_small_kernel), step 5 runs out of LDS (bh_com_small_kernel) and the walk takes one wave per group
-// (bh_walk_wide_kernel); the separate full-width kernels serve larger trees.
+// (bh_prep_small_kernel) and the walk takes one wave per group (bh_walk_wide_kernel); the separate full-width
+// kernels serve larger trees.
 //
-// Everything is deterministic (no atomics decide any index) and nothing synchronises with the host.
+// Everything is deterministic (no atomic decides any index or any value) and nothing synchronises with the host.
 // Node order is Morton order, not the reference's insertion order; topology, boxes, body indices, masses
 // and centres of mass are identical to oracle_tree_build() (tests compare them by traversal).
 // Bodies EXACTLY on a split line: the reference's bounds are inclusive on all four sides
@@ -75,8 +76,6 @@ struct BhCounters {          // device-resident scalars of one build/walk
 #ifdef NBODY_WIDE_TIMING
     unsigned long long dbg[24];  // developer build: 100 MHz ticks at phase boundaries of the one-workgroup kernels
 #endif
-    int max_depth;           // deepest internal cell of this build (wave-reduced atomicMax in bh_nodes_kernel); published to
-                             // the host as the hint for how many centre-of-mass launches the NEXT build needs
     int valid_part[64];      // small-N build: in-box bodies counted by bh_keys_kernel (one atomic per wave, spread over 64
                              // counters), summed by bh_prep_small_kernel, zeroed by bh_nodes_kernel for the next build
 };
@@ -87,6 +86,7 @@ struct BhTree {
     int2* __restrict__ B;
     uint8_t* __restrict__ depth;         // per internal cell
     int* __restrict__ self;              // per internal cell: its node index
+    int* pend;                           // per internal cell: internal children not yet finished (-1: it has none), bh_com_climb_kernel
     int cap_internal;
     int com_reciprocal;                  // 1: com = sum * (1/mass) as main.cpp:173-175 does; 0: sum / mass (benchmark.cpp:139-140)
 };
@@ -184,7 +184,6 @@ __device__ __forceinline__ void bh_reset_counters(BhCounters* __restrict__ ctr, 
     ctr->visits = 0;
     ctr->accepts = 0;
     ctr->wave_iters = 0;
-    ctr->max_depth = 0;
 }
 
 __global__ void bh_reset_kernel(BhCounters* __restrict__ ctr, float root_half0)
@@ -630,7 +629,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
                                                             const float* __restrict__ py, BhTree t,
                                                             BhCounters* __restrict__ ctr, int* __restrict__ overflow_host,
                                                             const uint64_t* __restrict__ keys_unmerged,
-                                                            const int* __restrict__ vals_unmerged, int track_depth)
+                                                            const int* __restrict__ vals_unmerged)
 {
     // small-N build: without second instances the merged arrays were never written, they ARE the sorted primaries
     if (keys_unmerged != nullptr && ctr->ghosts == 0) { keys = keys_unmerged; vals = vals_unmerged; }
@@ -644,7 +643,6 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
         // the build's verdict goes to a host-mapped word, so that nbody_sync needs no device-to-host copy (the tie
         // buffer's overflow, 2, was set by the kernels before this one)
         overflow_host[0] = I > t.cap_internal ? 1 : ctr->overflow;
-        overflow_host[1] = I < t.cap_internal ? I : t.cap_internal;     // hint for the NEXT build's choice of COM pass
         for (int k = 0; k < 64; ++k) ctr->valid_part[k] = 0;            // everybody has read ctr->valid by now
         if (M < 2) {                                           // degenerate trees: root is a leaf / empty
             const int b = M == 1 ? vals[0] : -1;
@@ -675,15 +673,6 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
         t.self[0] = 0;
     }
     t.depth[c] = (uint8_t)d;
-    if (track_depth) {
-        // deepest cell of the build, for the next build's choice of centre-of-mass launches: one atomicMax per wave
-        // (live lanes only reach this point).  Only for trees of up to ~200 000 cells: 11 000 same-address atomics
-        // cost 0.08 ms at N = 10^6, more than the launches the hint saves there.
-        int dm = d;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dm = max(dm, __shfl_xor(dm, o, 64));
-        if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(true))) atomicMax(&ctr->max_depth, dm);
-    }
 
     // body range [i, e) of the cell and its quadrant boundaries
     const int e = d ? bh_gallop_lower_bound(keys, i + 1, M, (prefix + 1) << shift) : M;
@@ -695,6 +684,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
     for (int q = 1; q < 4; ++q) s[q] = bh_gallop_lower_bound(keys, s[q - 1], e, ((prefix << 2) | (uint64_t)q) << cshift);
 
     const float mx = (tlx + brx) / 2.0f;
+    int internal_children = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int node = 1 + 4 * c + q;
@@ -710,6 +700,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
             if (cc < t.cap_internal) {
                 child_base = 1 + 4 * cc;
                 t.self[cc] = node;
+                ++internal_children;
             } else {                                           // pool exhausted: keep one body (benchmark.cpp:102)
                 body = vals[sq];
             }
@@ -739,6 +730,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
         t.A[node] = make_float4(cx, cy, cm, width);
         t.B[node] = make_int2(child_base, body);
     }
+    t.pend[c] = internal_children ? internal_children : -1;
 }
 
 // Read-back only (nbody_bh_tree_nodes): the box {tlX, tlY, brX, brY} of every node, recomputed from the topology —
@@ -766,7 +758,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_box_kernel(BhTree t, const BhCoun
     box[node] = make_float4(tlx, tly, brx, bry);
 }
 
-// 5. centre of mass, one launch per depth (deepest first) ---------------------------------------------------
+// 5. centre of mass -----------------------------------------------------------------------------------------
 __device__ __forceinline__ void bh_com_cell(const BhTree& t, int c)
 {
     const int self = t.self[c];
@@ -790,12 +782,11 @@ __device__ __forceinline__ void bh_com_cell(const BhTree& t, int c)
     rec[0] = cx; rec[1] = cy; rec[2] = ms;
 }
 
-// One thread per 4 cells (one 32-bit load of their depth bytes): a quarter of the threads of a launch per pool
-// slot, short serial tails.
-__global__ __launch_bounds__(kBhBlock) void bh_com_kernel(BhTree t, const BhCounters* __restrict__ ctr, int d, int min_internal)
+// One launch per depth, deepest first (trees of more than 2^21 bodies).  One thread per 4 cells (one 32-bit load of
+// their depth bytes): a quarter of the threads of a launch per pool slot, short serial tails.
+__global__ __launch_bounds__(kBhBlock) void bh_com_kernel(BhTree t, const BhCounters* __restrict__ ctr, int d)
 {
     const int I = ctr->internal;
-    if (I <= min_internal) return;                              // done by bh_com_small_kernel
     const int c4 = (blockIdx.x * kBhBlock + threadIdx.x) * 4;
     if (c4 >= I) return;
     const unsigned x = *reinterpret_cast<const unsigned*>(t.depth + c4) ^ (0x01010101u * (unsigned)d);
@@ -805,144 +796,69 @@ __global__ __launch_bounds__(kBhBlock) void bh_com_kernel(BhTree t, const BhCoun
         if (((x >> (8 * k)) & 0xFFu) == 0 && c4 + k < I) bh_com_cell(t, c4 + k);
 }
 
-// The per-depth launches cover depths below `top`, chosen by the host from the deepest cell of the PREVIOUS build (+2).
-// This one launch, enqueued before them, is the safety net for a tree that has grown deeper since: one workgroup,
-// level loop over every depth >= top — nothing to do (one load) in the expected case, slow but correct otherwise.
-// It also publishes this build's deepest cell to the host-mapped hint word for the next build.
-__global__ __launch_bounds__(1024) void bh_com_deep_kernel(BhTree t, const BhCounters* __restrict__ ctr, int top, int* __restrict__ hint_host)
-{
-    const int md = ctr->max_depth;                 // 0 when the node kernel does not track it: then top is 31 and
-    if (threadIdx.x == 0) hint_host[2] = md;       // this kernel has nothing to cover
-    if (md < top) return;
-    const int I = ctr->internal;
-    for (int d = md; d >= top; --d) {
-        for (int c = threadIdx.x; c < I; c += 1024)
-            if (t.depth[c] == d) bh_com_cell(t, c);
-        __syncthreads();
-    }
-}
-
-// Small trees: all depths in ONE launch of one workgroup (31 launches of a few microseconds each are most of a
-// Barnes-Hut step at N = 10 000).
+// All depths in ONE launch, no level barrier: a cell without internal children is evaluated at once; its thread then
+// counts itself off at the parent (one atomic on the parent's counter of unfinished internal children, set by
+// bh_nodes_kernel), and whoever arrives LAST evaluates the parent and climbs on.  Every cell is evaluated exactly once,
+// by one thread, from finished children in the fixed child order: the bits do not depend on who does it.  No thread
+// waits for another (nothing to hang on); a thread's chain is at most the tree's depth.  ~2 us per level of the
+// critical path instead of one 4.5-us launch per depth: N = 10 000 55 (one workgroup, results in LDS: round 2's first
+// version) -> 22 us, N = 10^6 143 (31 launches) -> 109 us; above ~2 x 10^6 bodies the per-depth launches win again
+// (their loads hit the L2), so the host switches there.
 //
-// Up to kBhComLds cells the level loop runs out of LDS: the cells are counting-sorted by depth (a 2-byte order list),
-// every level is then a dense run of that list, and a finished cell leaves {comX, comY, mass} in LDS (12 B per cell)
-// for its parent one level up — no global round trip between a child and its parent, one barrier per non-empty level.
-// Each thread requests the child records of its NEXT cell from global memory before it evaluates the current one.
-// Same expressions in the same child order as bh_com_cell, so the bits are the same.
-constexpr int kBhComBlock = 1024;                             // 16 waves: twice the loads in flight of 8
-constexpr int kBhComLds = 11264;                              // cells: (3 x 4 + 2) B x 11264 = 154 KB of the CU's 160 KB LDS
-
-// this thread's next slot of the depth-sorted order list (levels from the deepest up); false when it has none left
-__device__ __forceinline__ bool bh_com_next(const int* lstart, const int* lend, int tid, int& d, int& s)
+// Visibility across workgroups, which may sit on different XCDs (one L2 each): the children's results are written
+// with device-scope stores and read with device-scope loads (`sc1`: write through to / read from the level all XCDs
+// share), the stores are waited for (s_waitcnt vmcnt(0)) before the count-off atomic is issued, and the parent's loads
+// are issued after that atomic has returned.  That is the LLVM AMDGPU memory model's agent-scope release/acquire
+// sequence for gfx942/gfx950 minus its two cache-wide operations (buffer_wbl2 / buffer_inv), which exist for data
+// written or read with ORDINARY stores and loads — there is none here.  With them (a plain __threadfence() on either
+// side of the atomic) the N = 10^6 build takes 3.2 ms instead of 0.52: every fence writes back / invalidates the whole
+// L2 for everybody.
+__device__ __forceinline__ void bh_com_cell_agent(const BhTree& t, int c)
 {
-    s += kBhComBlock;
-    while (d >= 0 && s >= lend[d]) {
-        --d;
-        if (d >= 0) s = lstart[d] + tid;
+    const int self = t.self[c];
+    unsigned long long xy[4];
+    unsigned mz[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned long long* p = reinterpret_cast<const unsigned long long*>(t.A + 1 + 4 * c + q);
+        xy[q] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mz[q] = __hip_atomic_load(reinterpret_cast<const unsigned*>(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    return d >= 0;
+    float ms = 0.0f, sx = 0.0f, sy = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {          // as bh_com_cell
+        const float ax = __uint_as_float((unsigned)xy[q]), ay = __uint_as_float((unsigned)(xy[q] >> 32)), az = __uint_as_float(mz[q]);
+        ms = ms + az;
+        sx = __builtin_fmaf(ax, az, sx);
+        sy = __builtin_fmaf(ay, az, sy);
+    }
+    float cx = 0.0f, cy = 0.0f;
+    if (ms > 0.0f) {
+        if (t.com_reciprocal) { const float inv = 1.0f / ms; cx = sx * inv; cy = sy * inv; }
+        else                  { cx = sx / ms; cy = sy / ms; }
+    }
+    unsigned long long* rec = reinterpret_cast<unsigned long long*>(t.A + self);
+    __hip_atomic_store(rec, (unsigned long long)__float_as_uint(cx) | ((unsigned long long)__float_as_uint(cy) << 32), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned*>(rec + 1), __float_as_uint(ms), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(kBhComBlock) void bh_com_small_kernel(BhTree t, const BhCounters* __restrict__ ctr,
-                                                                   int* __restrict__ hint_host)
+__global__ __launch_bounds__(kBhBlock) void bh_com_climb_kernel(BhTree t, const BhCounters* __restrict__ ctr)
 {
     const int I = ctr->internal;
-    if (threadIdx.x == 0 && hint_host) hint_host[2] = ctr->max_depth;
-    __shared__ __align__(16) unsigned char lds[14 * kBhComLds];    // LDS path: x, y, mass, order; level loop: depths
-    __shared__ int lstart[kBhLevels + 1], lend[kBhLevels + 1];
-    const int tid = threadIdx.x;
-    if (I <= kBhComLds) {
-        float* lx = reinterpret_cast<float*>(lds);
-        float* ly = lx + kBhComLds;
-        float* lm = ly + kBhComLds;
-        unsigned short* order = reinterpret_cast<unsigned short*>(lm + kBhComLds);
-        // counting sort of the cells by depth, deepest level first (LDS atomics; a wave-aggregated variant with one
-        // atomic per wave and depth was measured slower: its ballot/shuffle loop costs more than the conflicts)
-        BhCounters* dbg = const_cast<BhCounters*>(ctr); (void)dbg;
-        BH_DBG_TICK(dbg, 8);
-        if (tid <= kBhLevels) lend[tid] = 0;
-        __syncthreads();
-        for (int c = tid; c < I; c += kBhComBlock) atomicAdd(&lend[t.depth[c]], 1);
-        __syncthreads();
-        if (tid == 0) {
-            int run = 0;
-            for (int d = kBhLevels - 1; d >= 0; --d) { lstart[d] = run; run += lend[d]; lend[d] = lstart[d]; }
-        }
-        __syncthreads();
-        for (int c = tid; c < I; c += kBhComBlock) order[atomicAdd(&lend[t.depth[c]], 1)] = (unsigned short)c;
-        __syncthreads();                                           // level d is order[lstart[d] .. lend[d])
-        BH_DBG_TICK(dbg, 9);
-        float4 a0, a1, a2, a3, n0, n1, n2, n3;
-        int cc0, cc1, cc2, cc3, self, cell, nc0, nc1, nc2, nc3, nself, ncell;
-#define BH_COM_FETCH(SLOT, CELL, A0, A1, A2, A3, C0, C1, C2, C3, SELF)                                 \
-        do {                                                                                           \
-            CELL = order[SLOT];                                                                        \
-            const float4* ap_ = t.A + 1 + 4 * CELL;                                                    \
-            const int2* bp_ = t.B + 1 + 4 * CELL;                                                      \
-            A0 = ap_[0]; A1 = ap_[1]; A2 = ap_[2]; A3 = ap_[3];                                        \
-            const int b0_ = bp_[0].x, b1_ = bp_[1].x, b2_ = bp_[2].x, b3_ = bp_[3].x;                  \
-            C0 = b0_ >= 0 ? (b0_ - 1) >> 2 : -1; C1 = b1_ >= 0 ? (b1_ - 1) >> 2 : -1;                  \
-            C2 = b2_ >= 0 ? (b2_ - 1) >> 2 : -1; C3 = b3_ >= 0 ? (b3_ - 1) >> 2 : -1;                  \
-            SELF = t.self[CELL];                                                                       \
-        } while (0)
-        int cd = kBhLevels - 1, cs = lstart[kBhLevels - 1] + tid - kBhComBlock;
-        bool have = bh_com_next(lstart, lend, tid, cd, cs);
-        if (have) BH_COM_FETCH(cs, cell, a0, a1, a2, a3, cc0, cc1, cc2, cc3, self);
-        int nd = cd, ns = cs;
-        bool have_next = have && bh_com_next(lstart, lend, tid, nd, ns);
-        if (have_next) BH_COM_FETCH(ns, ncell, n0, n1, n2, n3, nc0, nc1, nc2, nc3, nself);
-        BH_DBG_TICK(dbg, 10);
-        for (int lvl = kBhLevels - 1; lvl >= 0; --lvl) {
-            if (lend[lvl] == lstart[lvl]) continue;                // block-uniform
-            while (have && cd == lvl) {
-                float ms = 0.0f, sx = 0.0f, sy = 0.0f;
-#define BH_COM_ADD(CC, A)                                                                              \
-                do {                                                                                   \
-                    const float x_ = CC >= 0 ? lx[CC] : A.x, y_ = CC >= 0 ? ly[CC] : A.y;              \
-                    const float m_ = CC >= 0 ? lm[CC] : A.z;                                           \
-                    ms = ms + m_; sx = __builtin_fmaf(x_, m_, sx); sy = __builtin_fmaf(y_, m_, sy);    \
-                } while (0)
-                BH_COM_ADD(cc0, a0);                            // benchmark.cpp:126-135 in child order, as bh_com_cell
-                BH_COM_ADD(cc1, a1);
-                BH_COM_ADD(cc2, a2);
-                BH_COM_ADD(cc3, a3);
-#undef BH_COM_ADD
-                float cx = 0.0f, cy = 0.0f;
-                if (ms > 0.0f) {                                // benchmark.cpp:137-141
-                    if (t.com_reciprocal) { const float inv = 1.0f / ms; cx = sx * inv; cy = sy * inv; }
-                    else                  { cx = sx / ms; cy = sy / ms; }
-                }
-                lx[cell] = cx; ly[cell] = cy; lm[cell] = ms;
-                float* rec = reinterpret_cast<float*>(t.A + self);
-                rec[0] = cx; rec[1] = cy; rec[2] = ms;
-                have = have_next; cd = nd; cs = ns;
-                a0 = n0; a1 = n1; a2 = n2; a3 = n3; cc0 = nc0; cc1 = nc1; cc2 = nc2; cc3 = nc3; self = nself; cell = ncell;
-                if (have_next) {
-                    have_next = bh_com_next(lstart, lend, tid, nd, ns);
-                    if (have_next) BH_COM_FETCH(ns, ncell, n0, n1, n2, n3, nc0, nc1, nc2, nc3, nself);
-                }
-            }
-            bh_lds_barrier();                                      // level lvl is in LDS before level lvl-1 reads it
-        }
-#undef BH_COM_FETCH
-        BH_DBG_TICK(dbg, 11);
-        return;
-    }
-    // Larger trees: level loop over global memory (depths staged in LDS while they fit).  Slow — the host enqueues
-    // this kernel only when the previous build's tree was small (nbody_capi.hip), so this is the safety net for a
-    // tree that has just outgrown the LDS path, not a path anyone should live on.
-    const bool staged = I <= (int)sizeof(lds);
-    uint8_t* dl = lds;
-    if (staged) {
-        for (int c = threadIdx.x; c < I; c += kBhComBlock) dl[c] = t.depth[c];
-        __syncthreads();
-    }
-    for (int d = kBhLevels - 1; d >= 0; --d) {                 // a level without cells costs one barrier
-#pragma unroll 4
-        for (int c = threadIdx.x; c < I; c += kBhComBlock)
-            if ((staged ? dl[c] : t.depth[c]) == d) bh_com_cell(t, c);
-        __syncthreads();        // one workgroup: a barrier (with its LDS/global fence) orders level d before d-1
+    int c = blockIdx.x * kBhBlock + threadIdx.x;
+    if (c >= I) return;
+    if (t.pend[c] != -1) return;                   // has internal children: the last of them to finish takes it
+    for (int hop = 0; hop <= kBhLevels; ++hop) {
+        bh_com_cell_agent(t, c);
+        if (c == 0) break;
+        const int p = (t.self[c] - 1) >> 2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // compiler: nothing moves below
+        __builtin_amdgcn_s_waitcnt(0);             // the result stores are acknowledged before the count-off is issued
+        const int before = __hip_atomic_fetch_sub(&t.pend[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // compiler: nothing moves above
+        if (before != 1) break;
+        c = p;
     }
 }
 

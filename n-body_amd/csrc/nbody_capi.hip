@@ -55,7 +55,7 @@ struct Profiler {
 };
 
 constexpr int kMaxSlices = 64;
-constexpr int kBhTrackDepthMax = 262144;    // bodies: above, the deepest cell is not tracked and all 31 depths get a launch
+constexpr int kBhClimbMax = 1 << 21;         // bodies: up to here the centre-of-mass pass is ONE launch (bh_com_climb_kernel)
 constexpr float kBhSortedThetaScale = 0.6f;     // tools/bh_sorted_scale.py, profiles/r2_bh_sorted_scale.txt
 constexpr int kBhWideMaxGroups = 4096;      // <= 32 768 targets: the walk takes one wave per group (measured crossover)
 constexpr size_t kMaxEventsPerClass = 4096;
@@ -123,8 +123,6 @@ struct nbody_ctx {
         int* own_order = nullptr;
         void* own_sort_tmp = nullptr;
         size_t own_sort_bytes = 0;
-        int com_lds_pass = -1;                       // which centre-of-mass pass the last build enqueued (-1: none yet)
-        int com_top = -1;                            // per-depth pass: depths below this have their own launch
         void *sort_tmp = nullptr, *scan_tmp = nullptr;
         size_t sort_bytes = 0, scan_bytes = 0;
         int64_t node_cap = 0;
@@ -239,29 +237,6 @@ int enqueue_integrate(nbody_ctx* ctx, int advance)
 }
 
 
-// 1: the one-workgroup LDS pass, 0: one launch per depth (see enqueue_bh_build).  Hint = the previous build's cell
-// count, with hysteresis so that a tree hovering at the limit does not re-capture the step graph every step.
-int choose_com_pass(nbody_ctx* ctx)
-{
-    auto& b = ctx->bh;
-    if (b.tree.cap_internal <= kBhComLds) return 1;
-    const int hint = b.overflow_host[1] > 0 ? b.overflow_host[1] : (int)(0.73 * ctx->cfg.num_bodies);
-    if (b.com_lds_pass == 1) return hint <= kBhComLds ? 1 : 0;
-    return hint <= kBhComLds - kBhComLds / 8 ? 1 : 0;
-}
-
-// Depths [0, top) get their own centre-of-mass launch; hint = the previous build's deepest cell.  Hysteresis: keep
-// the current choice while it covers the hint with 1..4 levels to spare (a captured graph holds the choice).
-int choose_com_top(nbody_ctx* ctx)
-{
-    auto& b = ctx->bh;
-    const int hint = b.overflow_host[2];
-    if (hint < 0 || ctx->cfg.num_bodies > kBhTrackDepthMax) return kBhLevels;
-    if (b.com_top >= 0 && b.com_top >= hint + 2 && b.com_top <= hint + 5) return b.com_top;
-    const int top = hint + 3;
-    return top < kBhLevels ? top : kBhLevels;
-}
-
 // Barnes-Hut step = build (keys -> sort -> cells -> nodes -> centre of mass) + walk, benchmark.cpp:354-403.
 int enqueue_bh_build(nbody_ctx* ctx)
 {
@@ -306,23 +281,17 @@ int enqueue_bh_build(nbody_ctx* ctx)
     const dim3 grid_c((b.tree.cap_internal + kBhBlock - 1) / kBhBlock);
     bh_nodes_kernel<<<grid_c, blk, 0, s>>>(b.keys_merged, b.vals_merged, b.cnt, b.base, b.owner, nm, ctx->m, ctx->px, ctx->py,
                                            b.tree, b.ctr, b.overflow_dev, fused ? b.keys_sorted : nullptr,
-                                           fused ? b.vals_sorted : nullptr, n <= kBhTrackDepthMax ? 1 : 0);
-    // centre of mass.  Two passes, each correct for ANY tree: one workgroup with the results in LDS (fast up to
-    // kBhComLds cells, a slow level loop beyond) or one launch per depth (31 launches of ~4.5 us, the only sane way for
-    // a big tree).  Which one is enqueued is a HOST decision, so it is taken from the cell count of the previous
-    // build (the node kernel leaves it in host-mapped memory; 0.73 cells per body for the reference's disc when there
-    // is no previous build).  A captured graph keeps its choice until the hint crosses the threshold.
-    b.com_lds_pass = choose_com_pass(ctx);
-    if (b.com_lds_pass) {
-        bh_com_small_kernel<<<1, kBhComBlock, 0, s>>>(b.tree, b.ctr, b.overflow_dev);
+                                           fused ? b.vals_sorted : nullptr);
+    // centre of mass: one launch in which the last child to finish evaluates its parent; for very large trees one
+    // launch per depth (31 launches of >= 4.5 us, but their loads hit the L2: faster above ~2 x 10^6 bodies)
+    const char* climb_env = std::getenv("NBODY_BH_CLIMB_MAX");          // developer/test switch, read per enqueue
+    const int climb_max = climb_env ? std::atoi(climb_env) : kBhClimbMax;
+    if (n <= climb_max) {
+        bh_com_climb_kernel<<<grid_c, blk, 0, s>>>(b.tree, b.ctr);
     } else {
-        // one launch per depth below `top` (the previous build's deepest cell + 2), one safety-net launch for
-        // everything at or above it: 31 launches -> ~20 at N = 65 536, ~25 at N = 10^6
-        b.com_top = choose_com_top(ctx);
         const dim3 grid_com((unsigned)((b.tree.cap_internal + 4 * kBhBlock - 1) / (4 * kBhBlock)));
-        bh_com_deep_kernel<<<1, 1024, 0, s>>>(b.tree, b.ctr, b.com_top, b.overflow_dev);
-        for (int d = b.com_top - 1; d >= 0; --d)
-            bh_com_kernel<<<grid_com, blk, 0, s>>>(b.tree, b.ctr, d, -1);
+        for (int d = kBhLevels - 1; d >= 0; --d)
+            bh_com_kernel<<<grid_com, blk, 0, s>>>(b.tree, b.ctr, d);
     }
     HIP_TRY(hipGetLastError());
     return profile_end(ctx, 2, ep);
@@ -572,11 +541,11 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
         HIP_TRY_C(hipMalloc((void**)&b.owner, sizeof(int) * (size_t)b.tree.cap_internal));
         HIP_TRY_C(hipMalloc((void**)&b.tree.depth, (size_t)b.tree.cap_internal + 16));   // read 16 bytes at a time
         HIP_TRY_C(hipMalloc((void**)&b.tree.self, sizeof(int) * (size_t)b.tree.cap_internal));
+        HIP_TRY_C(hipMalloc((void**)&b.tree.pend, sizeof(int) * (size_t)b.tree.cap_internal));
         HIP_TRY_C(hipMalloc((void**)&b.ctr, sizeof(BhCounters)));
         HIP_TRY_C(hipMemset(b.ctr, 0, sizeof(BhCounters)));
         HIP_TRY_C(hipHostMalloc((void**)&b.overflow_host, 4 * sizeof(int), hipHostMallocMapped));
-        b.overflow_host[0] = b.overflow_host[1] = 0;           // [0] overflow flag, [1] internal cells of the last build,
-        b.overflow_host[2] = -1;                               // [2] its deepest cell (-1: no build yet)
+        b.overflow_host[0] = 0;                                // the build's verdict, read by nbody_sync without a copy
         HIP_TRY_C(hipHostGetDevicePointer((void**)&b.overflow_dev, b.overflow_host, 0));
         HIP_TRY_C(hipMalloc((void**)&b.grp_visits, sizeof(int) * ((size_t)n / 8 + 1)));
         HIP_TRY_C(hipMalloc((void**)&b.grp_accepts, sizeof(int) * ((size_t)n / 8 + 1)));
@@ -614,7 +583,7 @@ void nbody_destroy(nbody_ctx* ctx)
     {
         auto& b = ctx->bh;
         void* ptrs[] = {b.keys, b.keys_sorted, b.vals, b.vals_sorted, b.cnt, b.base, b.tree.A, b.tree.B,
-                        b.tree.depth, b.tree.self, b.ctr, b.tie, b.owner, b.gfx, b.gfy, b.gld, b.pld, b.glo, b.ghi, b.gpos, b.tie_table, b.sort_tmp, b.scan_tmp, b.gkeys, b.gkeys_sorted, b.gvals,
+                        b.tree.depth, b.tree.self, b.tree.pend, b.ctr, b.tie, b.owner, b.gfx, b.gfy, b.gld, b.pld, b.glo, b.ghi, b.gpos, b.tie_table, b.sort_tmp, b.scan_tmp, b.gkeys, b.gkeys_sorted, b.gvals,
                         b.gvals_sorted, b.keys_merged, b.vals_merged, b.gsort_tmp, b.grp_visits, b.grp_accepts,
                         b.own_keys_sorted, b.own_order, b.own_sort_tmp};
         for (void* p : ptrs)
@@ -766,9 +735,6 @@ void drop_step_graph(nbody_ctx* ctx)
 bool ensure_step_graph(nbody_ctx* ctx)
 {
     if (!ctx->cfg.use_barnes_hut || ctx->prof.on || ctx->graph_failed || std::getenv("NBODY_NO_GRAPH")) return false;
-    // the captured build holds one of the two centre-of-mass passes: capture again when the tree has outgrown it
-    if (ctx->step_graph && (ctx->bh.com_lds_pass != choose_com_pass(ctx) ||
-                            (!ctx->bh.com_lds_pass && ctx->bh.com_top != choose_com_top(ctx)))) drop_step_graph(ctx);
     if (ctx->step_graph && ctx->step_graph_stream == ctx->stream) return true;
     drop_step_graph(ctx);
     hipGraph_t graph = nullptr;

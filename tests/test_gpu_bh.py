@@ -235,13 +235,16 @@ def test_wide_walk_equals_the_group_per_8_lanes_walk(nb, O, n, theta, fast, monk
         assert np.array_equal(ax1, ox.astype(np.float32)) and np.array_equal(ay1, oy.astype(np.float32))
 
 
-def test_tree_that_outgrows_the_previous_builds_depth_hint(nb, O):
-    """The per-depth centre-of-mass launches cover the depths the PREVIOUS build needed (+2; the node kernel leaves its
-    deepest cell in host-mapped memory), one safety-net launch covers everything deeper.  First build: a shallow tree
-    (a jittered lattice, depth ~9).  Then the same context gets a state with two bodies 2e-5 apart (depth ~26): the
-    stale hint must cost time, not results — tree and accelerations equal the oracle's, and so does the build after
-    it, which has the fresh hint."""
-    n = 40000                                                      # > 11 264 cells: the per-depth pass
+@pytest.mark.parametrize("per_depth", [False, True])
+def test_deep_tree_after_a_shallow_one(nb, O, per_depth, monkeypatch):
+    """Both centre-of-mass passes (the one-launch climb and, for trees of more than 2^21 bodies, one launch per depth —
+    forced here through NBODY_BH_CLIMB_MAX) must not depend on anything a previous build left behind.  First build: a
+    shallow tree (a jittered lattice, depth ~9).  Then the same context gets a state with two bodies 2e-5 apart
+    (depth ~26, a chain of 17 cells with one internal child each — the longest climb a single thread makes): tree and
+    accelerations equal the oracle's, twice."""
+    if per_depth:
+        monkeypatch.setenv("NBODY_BH_CLIMB_MAX", "0")
+    n = 40000
     rng = np.random.default_rng(12)
     side = 200
     gx, gy = np.meshgrid(np.arange(side), np.arange(side))
@@ -259,7 +262,7 @@ def test_tree_that_outgrows_the_previous_builds_depth_hint(nb, O):
         sim.upload_state(deep.posX, deep.posY, deep.velX, deep.velY)
         ot = O.Tree(n).build(deep, 400.0)
         assert ot.stats()["depth"] >= ot_depth_of(shallow) + 8
-        for _ in range(2):                                         # stale hint, then fresh hint
+        for _ in range(2):
             sim.compute_accel().sync()
             ax, ay = sim.accel()
             tree = sim.bh_tree()
@@ -267,6 +270,25 @@ def test_tree_that_outgrows_the_previous_builds_depth_hint(nb, O):
             ox, oy, ocnt = ot.accel(deep, 1.0)
             assert sim.bh_counters() == ocnt
             assert np.array_equal(ax, ox.astype(np.float32)) and np.array_equal(ay, oy.astype(np.float32))
+
+
+def test_centre_of_mass_pass_is_deterministic_over_repeated_builds(nb, O):
+    """bh_com_climb_kernel: each cell is evaluated by whichever thread is the last to finish one of its children.  WHO
+    that is varies from launch to launch; the result must not (and a child record read before it was visible would show
+    up here as a different mass).  40 builds of the same clustered input, every node's {mass, comX, comY} bit-equal to
+    the first build's — which test_clustered_plummer_theta05 and the full-size tests compare with the oracle."""
+    n = 300_000
+    b = O.init_plummer(n, scale=50.0, seed=7)
+    with nb.NBodySim(n, useBarnesHut=True, useParallel=False) as sim:
+        sim.upload(*b.arrays())
+        first = None
+        for _ in range(40):
+            sim.compute_accel().sync()
+            t = sim.bh_tree()
+            rec = np.stack([t["mass"], t["comX"], t["comY"]]).view(np.uint32)
+            if first is None:
+                first = rec
+            assert np.array_equal(rec, first)
 
 
 def ot_depth_of(pool):
