@@ -161,6 +161,60 @@ __device__ __forceinline__ int bh_valid_total(const BhCounters* __restrict__ ctr
     return m;
 }
 
+// 2 (small N). Sort by RANKING: rank(i) = #{j : (key_j, j) < (key_i, i)} counted by brute force, n^2 64-bit compares.  At
+// N = 10 000 that is 10^8 compares = 21 us in one launch (~14 SIMD cycles per wave-wide compare: v_cmp_lt_u64, the
+// add and a VCC wait state; a 32-bit borrow chain in its place was measured slower), against 35 us for the five
+// launches of a general device sort on an input this small (block sort + four merge passes, each launch-latency
+// bound).  Break-even at ~16 000 bodies, used up to kBhRankSortMax.  Stable by
+// construction (ties — bodies sharing a finest cell — order by index, as a stable radix sort leaves them), no atomic
+// decides anything: partial counts of the j-slices are ADDED into rank[i] (integer sums commute), and the workgroup
+// that arrives last at its i-tile (count-off as in bh_com_climb_kernel: adds acknowledged, then one atomic on the
+// tile's counter) reads the complete ranks with device-scope loads, scatters the tile and leaves rank[] and the
+// counter zero for the next build.
+constexpr int kBhRankChunk = 512;                   // keys staged in LDS per round
+constexpr int kBhRankSortMax = 12288;               // bodies (measured: -14 us at 10 000, +-0 at 16 384, +54 us at 32 768)
+
+__global__ __launch_bounds__(kBhBlock) void bh_ranksort_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals, int n,
+                                                               int j_per_slice, int* rank, int* done,
+                                                               uint64_t* __restrict__ keys_sorted, int* __restrict__ vals_sorted)
+{
+    __shared__ __align__(16) uint64_t tile[kBhRankChunk];
+    __shared__ int last;
+    const int tid = threadIdx.x;
+    const int ilo = blockIdx.x * kBhBlock, i = ilo + tid;
+    const bool live = i < n;
+    const uint64_t ki = keys[live ? i : n - 1];
+    const int j0 = blockIdx.y * j_per_slice, j1 = min(n, j0 + j_per_slice);
+    int cnt = 0;
+    for (int jb = j0; jb < j1; jb += kBhRankChunk) {
+#pragma unroll
+        for (int q = tid; q < kBhRankChunk; q += kBhBlock) tile[q] = jb + q < j1 ? keys[jb + q] : ~0ull;   // padding: never counted
+        __syncthreads();
+        // (key_j, j) < (key_i, i)  <=>  key_j < key_i + (j < i); keys have bit 62 or bit 63 clear below ~0: no overflow
+        if (jb + kBhRankChunk <= ilo || jb >= ilo + kBhBlock) {          // the whole chunk is on one side of the tile
+            const uint64_t t = ki + (jb < ilo ? 1u : 0u);
+#pragma unroll 8
+            for (int q = 0; q < kBhRankChunk; ++q) cnt += tile[q] < t ? 1 : 0;
+        } else {
+#pragma unroll 8
+            for (int q = 0; q < kBhRankChunk; ++q) cnt += tile[q] < ki + (jb + q < i ? 1u : 0u) ? 1 : 0;
+        }
+        __syncthreads();
+    }
+    if (live && cnt) __hip_atomic_fetch_add(&rank[i], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);                  // this wave's adds are acknowledged ...
+    __syncthreads();                                // ... and so are the other waves', before the tile is counted off
+    if (tid == 0) last = __hip_atomic_fetch_add(&done[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.y - 1;
+    __syncthreads();
+    if (!last) return;
+    if (live) {
+        const int r = __hip_atomic_load(&rank[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)r < (unsigned)n) { keys_sorted[r] = ki; vals_sorted[r] = vals[i]; }
+        rank[i] = 0;
+    }
+    if (tid == 0) done[blockIdx.x] = 0;
+}
+
 // large build: number of valid (in-box) bodies = first sorted index with the invalid bit set
 __global__ void bh_valid_kernel(const uint64_t* __restrict__ keys, int n, BhCounters* __restrict__ ctr)
 {
@@ -348,10 +402,9 @@ constexpr int kBhFixBlock = 1024;
 __device__ __forceinline__ void bh_tie_fixpoint_body(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
                                                      const float* __restrict__ px, const float* __restrict__ py,
                                                      const uint16_t* __restrict__ tie, BhCounters* __restrict__ ctr,
-                                                     const BhTies& T)
+                                                     const BhTies& T, const int M)
 {
     __shared__ int s_end;
-    const int M = ctr->valid;
     const float spread = ctr->root_half;
     int begin = 0;
     if (threadIdx.x == 0) { const int g = __hip_atomic_load(&ctr->ghosts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_end = g < T.gcap ? g : T.gcap; }
@@ -407,7 +460,7 @@ __global__ __launch_bounds__(kBhFixBlock) void bh_tie_fixpoint_kernel(const uint
                                                                       const uint16_t* __restrict__ tie, BhCounters* __restrict__ ctr,
                                                                       BhTies T)
 {
-    bh_tie_fixpoint_body(keys, vals, px, py, tie, ctr, T);
+    bh_tie_fixpoint_body(keys, vals, px, py, tie, ctr, T, ctr->valid);
 }
 
 // merge sorted primaries [n] and sorted second instances [gcap] into one sorted array [n + gcap]
@@ -529,9 +582,9 @@ __global__ __launch_bounds__(kBhFixBlock) void bh_prep_small_kernel(const uint64
             if (first[u] != kBhLevels) bh_ties_one(i0 + u * kBhFixBlock, M0, keys, vals, px, py, tie, ctr, T);
     }
     __syncthreads();            // one workgroup = one CU = one L1: a barrier is all the ordering the phases need
-    if (tid == 0) ctr->valid = M0;
     BH_DBG_TICK(ctr, 1);
-    bh_tie_fixpoint_body(keys, vals, px, py, tie, ctr, T);
+    // (M0 by value: ctr->valid is only written further down, by one thread; reading it here would race with that)
+    bh_tie_fixpoint_body(keys, vals, px, py, tie, ctr, T, M0);
     BH_DBG_TICK(ctr, 2);
     const int ghosts = __hip_atomic_load(&ctr->ghosts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int gmax = T.gcap < kBhSmallGhosts ? T.gcap : kBhSmallGhosts;

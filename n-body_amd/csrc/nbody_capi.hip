@@ -123,6 +123,7 @@ struct nbody_ctx {
         int* own_order = nullptr;
         void* own_sort_tmp = nullptr;
         size_t own_sort_bytes = 0;
+        int *rank = nullptr, *rank_done = nullptr;   // small-N rank sort: partial ranks [n], per-tile arrival counters
         void *sort_tmp = nullptr, *scan_tmp = nullptr;
         size_t sort_bytes = 0, scan_bytes = 0;
         int64_t node_cap = 0;
@@ -257,8 +258,18 @@ int enqueue_bh_build(nbody_ctx* ctx)
     const bool fused = n <= kBhSmallMax && b.gcap <= kBhSmallGhosts && !std::getenv("NBODY_BH_NO_FUSE");
     bh_keys_kernel<<<grid_n, blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr, ctx->cfg.spread, adaptive ? 0 : 1, b.keys, b.vals, b.tie,
                                           b.gkeys, b.gvals, b.gcap, b.tie_table, b.tie_table_size, fused ? 1 : 0);
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, b.keys, b.keys_sorted, b.vals, b.vals_sorted, n,
-                                               0, 64, s));
+    const char* rank_env = std::getenv("NBODY_BH_RANKSORT_MAX");         // developer/test switch
+    if (fused && n <= (rank_env ? std::atoi(rank_env) : kBhRankSortMax)) {
+        // small N: rank by brute-force counting, one launch.  ~1024 workgroups: i-tiles of 256 x j-slices
+        const int tiles = (int)grid_n.x;
+        int slices = 1024 / tiles < 1 ? 1 : (1024 / tiles > 64 ? 64 : 1024 / tiles);
+        const int per = ((n + slices - 1) / slices + kBhRankChunk - 1) / kBhRankChunk * kBhRankChunk;
+        slices = (n + per - 1) / per;
+        bh_ranksort_kernel<<<dim3(grid_n.x, slices), blk, 0, s>>>(b.keys, b.vals, n, per, b.rank, b.rank_done, b.keys_sorted, b.vals_sorted);
+    } else {
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, b.keys, b.keys_sorted, b.vals, b.vals_sorted, n,
+                                                   0, 64, s));
+    }
     // bodies exactly on a split line get a second instance (inclusive bounds, benchmark.cpp:83-85)
     BhTies ties{b.gkeys, b.gvals, b.gfx, b.gfy, b.gld, b.glo, b.ghi, b.gpos, b.pld, b.tie_table, b.tie_table_size - 1, b.gcap};
     if (fused) {
@@ -542,6 +553,12 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
         HIP_TRY_C(hipMalloc((void**)&b.tree.depth, (size_t)b.tree.cap_internal + 16));   // read 16 bytes at a time
         HIP_TRY_C(hipMalloc((void**)&b.tree.self, sizeof(int) * (size_t)b.tree.cap_internal));
         HIP_TRY_C(hipMalloc((void**)&b.tree.pend, sizeof(int) * (size_t)b.tree.cap_internal));
+        if (n <= kBhRankSortMax) {                             // both stay zero between builds (the kernel re-zeroes them)
+            HIP_TRY_C(hipMalloc((void**)&b.rank, sizeof(int) * (size_t)n));
+            HIP_TRY_C(hipMalloc((void**)&b.rank_done, sizeof(int) * ((size_t)n / kBhBlock + 1)));
+            HIP_TRY_C(hipMemset(b.rank, 0, sizeof(int) * (size_t)n));
+            HIP_TRY_C(hipMemset(b.rank_done, 0, sizeof(int) * ((size_t)n / kBhBlock + 1)));
+        }
         HIP_TRY_C(hipMalloc((void**)&b.ctr, sizeof(BhCounters)));
         HIP_TRY_C(hipMemset(b.ctr, 0, sizeof(BhCounters)));
         HIP_TRY_C(hipHostMalloc((void**)&b.overflow_host, 4 * sizeof(int), hipHostMallocMapped));
@@ -583,7 +600,7 @@ void nbody_destroy(nbody_ctx* ctx)
     {
         auto& b = ctx->bh;
         void* ptrs[] = {b.keys, b.keys_sorted, b.vals, b.vals_sorted, b.cnt, b.base, b.tree.A, b.tree.B,
-                        b.tree.depth, b.tree.self, b.tree.pend, b.ctr, b.tie, b.owner, b.gfx, b.gfy, b.gld, b.pld, b.glo, b.ghi, b.gpos, b.tie_table, b.sort_tmp, b.scan_tmp, b.gkeys, b.gkeys_sorted, b.gvals,
+                        b.tree.depth, b.tree.self, b.tree.pend, b.rank, b.rank_done, b.ctr, b.tie, b.owner, b.gfx, b.gfy, b.gld, b.pld, b.glo, b.ghi, b.gpos, b.tie_table, b.sort_tmp, b.scan_tmp, b.gkeys, b.gkeys_sorted, b.gvals,
                         b.gvals_sorted, b.keys_merged, b.vals_merged, b.gsort_tmp, b.grp_visits, b.grp_accepts,
                         b.own_keys_sorted, b.own_order, b.own_sort_tmp};
         for (void* p : ptrs)
