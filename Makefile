@@ -15,7 +15,7 @@ $(LIB): $(CSRC)/nbody_capi.hip $(KERNEL_HDRS)
 	@mkdir -p $(PKG)/lib
 	$(HIPCC) $(HIPFLAGS) -shared $< -o $@ -ldl
 
-# developer build: bh_walk_wide_kernel returns per-phase ticks (tools/wide_timing.py)
+# developer build: bh_walk_quad_kernel returns per-phase ticks (tools/quad_timing.py)
 lib-timing: $(CSRC)/nbody_capi.hip $(KERNEL_HDRS)
 	@mkdir -p $(PKG)/lib
 	$(HIPCC) $(HIPFLAGS) -DNBODY_WIDE_TIMING -shared $< -o $(PKG)/lib/libnbody_amd_timing.so -ldl

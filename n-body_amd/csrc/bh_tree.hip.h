@@ -24,8 +24,8 @@
 //                          com = sum(com_k*m_k)/mass in child order (benchmark.cpp:122-141)
 //
 // Up to 32 768 bodies (the reference's default is 10 000) steps 2b-4a are one launch of one workgroup
-// (bh_prep_small_kernel) and the walk takes one wave per group (bh_walk_wide_kernel); the separate full-width
-// kernels serve larger trees.
+// (bh_prep_small_kernel), and up to ~50 000 bodies the walk gives every group four waves (bh_walk_quad_kernel); the
+// separate full-width kernels serve larger trees.
 //
 // Everything is deterministic (no atomic decides any index or any value) and nothing synchronises with the host.
 // Node order is Morton order, not the reference's insertion order; topology, boxes, body indices, masses
@@ -1078,26 +1078,33 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     }
 }
 
-// Wide walk (small N) ---------------------------------------------------------------------------------------------
-// Below ~32 768 bodies the walk above is a latency chain: one node record per visit, ~500 dependent visits per group,
-// ~0.5 us each, on a chip that is mostly idle (N = 10 000 is 1250 groups for 1024 SIMDs).  Here ONE WAVE takes ONE
-// group and all 64 lanes work on it: 8 slots x the group's 8 targets, every slot testing a different pending node.
+// Parallel walk (up to ~50 000 targets) ------------------------------------------------------------------------------
+// Below ~65 000 bodies the walk above is a latency chain: one node record per visit, ~500 dependent visits per group,
+// ~0.5 us each, on a chip that is mostly idle (N = 10 000 is 1250 groups for 1024 SIMDs).  Here a group gets a
+// workgroup of FOUR waves, and in every wave all 64 lanes work on it: 8 slots x the group's 8 targets, every slot
+// testing a different pending node.  When the group opens the root (every wave takes that vote itself), wave k takes the
+// subtree of root child 3-k — the reference pops child 3 first (benchmark.cpp:244) — on LDS lists of its own:
 //
-//   pass 1  traversal, order-free: pop up to 16 pending nodes (2 per slot), load their records together, take the
-//           reference's vote per slot (8-bit ballot field), append accepted nodes to a list and push the children of
-//           opened ones.  Every pending node carries its DFS position as a path key — digit 3-q per level, because the
-//           reference pops child 3 first (benchmark.cpp:244, :272-274) — so the ORDER in which nodes are tested is free;
-//   sort    the accepted (key, node) pairs by key in LDS (bitonic): now they are in the reference's visiting order;
-//   pass 2  8 accepted nodes at a time, one per slot: node kernel (benchmark.cpp:188-225) for the 8 targets, terms
-//           through LDS, every lane adds the 8 terms of its target IN ORDER.
+//   phase A, the four waves in parallel
+//     pass 1  traversal, order-free: pop up to 32 pending nodes (4 per slot), load their records together, take the
+//             reference's vote per slot (8-bit ballot field), append accepted nodes to a list and push the children of
+//             opened ones.  Every pending node carries its DFS position as a path key — digit 3-q per level, because
+//             the reference pops child 3 first (benchmark.cpp:244, :272-274) — so the ORDER in which nodes are tested
+//             is free;
+//     sort    the accepted (key, node) pairs by key (bitonic, in registers): now they are in the reference's visiting
+//             order;
+//     terms   node kernel (benchmark.cpp:188-225) of the first 96 accepted nodes for the 8 targets, kept in registers;
+//   phase B, wave after wave in the reference's order, wave k starting from the sums wave k-1 left in LDS
+//             the additions: 8 nodes per round, one per slot, terms through LDS, every lane adds the terms of its
+//             target IN ORDER; accepted nodes beyond the first 96 are evaluated here, 16 per round.
 //
 // Same arithmetic per (node, target) and the same summation order as bh_walk_kernel, so accelerations and the
-// visit/accept counters are bit-identical to it and to the oracle.  The lists live in LDS and are bounded; when a
-// traversal outgrows them it is abandoned and its root is split into its four children, each walked on its own, in
-// DFS order (a node whose lists overflow was opened, so this is exactly what the reference does with it).
-// LDS list capacities are template parameters (accepted nodes of one traversal, pending nodes): 1024/512 when the
-// launch is a single round anyway (19.5 KB, 2 waves per SIMD), 512/256 (10.5 KB and <= 128 VGPRs: 4 waves per SIMD)
-// when there are more groups than that holds.
+// visit/accept counters are bit-identical to it and to the oracle.  The lists live in LDS and are bounded (256 accepted,
+// 128 pending nodes per wave); a traversal that outgrows them is abandoned and its root split into its four children,
+// each walked on its own, in DFS order, when the wave's turn in phase B comes (a node whose lists overflow was opened,
+// so this is exactly what the reference does with it; the group's accept count of the previous walk tells a wave to
+// split up front instead).  A group that does not open the root (a leaf, an accepted or a massless root) is one visit,
+// done by wave 0 alone.  Waves only ever meet at workgroup barriers that all four pass the same number of times.
 constexpr int kWidePerSlot = 4;      // nodes tested per slot per iteration of pass 1
 constexpr int kWideRound = 2;        // nodes per slot per round of pass 2
 
@@ -1153,18 +1160,39 @@ __device__ __noinline__ void bh_wide_sort(unsigned long long* __restrict__ akey,
     for (int r = 0; r < R; ++r) anode[lane * R + r] = v[r];
 }
 
-template <bool kFast, int kAcc, int kStk>
-__global__ __launch_bounds__(64) void bh_walk_wide_kernel(const BhWalkArgs w)
+#ifndef NBODY_QUAD_WAVES
+#define NBODY_QUAD_WAVES 5
+#endif
+struct BhQuadLds {
+    unsigned long long pkey[128];
+    unsigned long long akey[256];
+    int pnode[128];
+    int anode[256];
+    float termx[8 * kWideRound][8], termy[8 * kWideRound][8];
+    int tasks[128];                  // 1 + 3 per level of splitting, 31 levels
+    unsigned char tdepth[128];
+};
+constexpr int kQuadAcc = 256, kQuadStk = 128;
+
+// one wave: LDS traffic of a wave is executed in order, so lanes exchanging data through LDS need no hardware barrier,
+// only the compiler must keep the order
+__device__ __forceinline__ void bh_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool kFast>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBODY_QUAD_WAVES, 8))) void bh_walk_quad_kernel(const BhWalkArgs w)
 {
 #pragma clang fp contract(off)
-    __shared__ unsigned long long pkey[kStk];
-    __shared__ int pnode[kStk];
-    __shared__ unsigned long long akey[kAcc];
-    __shared__ int anode[kAcc];
-    __shared__ float termx[8 * kWideRound][8], termy[8 * kWideRound][8];
-    __shared__ int tasks[128];
-    __shared__ unsigned char tdepth[128];
-    const int lane = threadIdx.x, slot = lane >> 3, t = lane & 7;
+    constexpr int kAcc = kQuadAcc, kStk = kQuadStk;
+    __shared__ BhQuadLds lds[4];
+    __shared__ float accx[8], accy[8];
+    __shared__ unsigned cnt_v, cnt_a;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, slot = lane >> 3, t = lane & 7;
+    BhQuadLds& S = lds[wv];
     const int pos = w.i_begin + (int)blockIdx.x * 8 + t;            // position in walk order; i: the body there
     const bool live = pos < w.i_end;
     const int pc = live ? pos : w.i_end - 1;
@@ -1176,39 +1204,35 @@ __global__ __launch_bounds__(64) void bh_walk_wide_kernel(const BhWalkArgs w)
     const unsigned long long below_slot = (1ull << (slot * 8)) - 1ull;
     float ax = 0.0f, ay = 0.0f;
     unsigned visits = 0, accepts = 0;                    // wave-uniform
-#ifdef NBODY_WIDE_TIMING                                 // developer build: 100 MHz ticks per phase instead of results
-    unsigned long long tk0 = __builtin_amdgcn_s_memrealtime(), tk1 = 0, tk2 = 0, tk3 = 0, tkx;
-    unsigned iters = 0;
-#define WIDE_TICK(acc) do { tkx = __builtin_amdgcn_s_memrealtime(); acc += tkx - tk0; tk0 = tkx; } while (0)
-#else
-#define WIDE_TICK(acc) do { } while (0)
-#endif
-    // How many levels to split up front: the group's accept count of the PREVIOUS walk (still in grp_accepts) says
-    // whether the whole tree fits the accept list; if not, starting with the root's children (grandchildren, ...) as
-    // separate traversals saves the abandoned attempt.  A hint only: a wrong one costs time, the overflow path below
-    // splits whatever still does not fit.
     int presplit = 0;
     {
         const int hint = w.grp_accepts[(w.i_begin >> 3) + blockIdx.x];
         for (int h = hint; h > kAcc - kAcc / 4 && presplit < 4; h >>= 2) ++presplit;
     }
-    int ntask = 1;
-    if (lane == 0) { tasks[0] = 0; tdepth[0] = 0; }
-    __syncthreads();
-    while (ntask > 0) {
-        const int root = tasks[--ntask];
-        const int rdepth = tdepth[ntask];
-        bool first_iter = true;
-        // ---- pass 1: which nodes does the reference accept below `root`? ----
-        int sp = 1, na = 0;
-        unsigned tv = 0;
-        bool overflow = false;
-        if (lane == 0) { pnode[0] = root; pkey[0] = 1ull; }
-        __syncthreads();
+
+    // vote of the 8 targets on one node record, per slot (the reference's, benchmark.cpp:248-266)
+    auto vote = [&](const float4& a, const int2& b, bool act, bool& accept, bool& open) {
+        const float dx = a.x - xi, dy = a.y - yi;
+        const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+        const float q = a.w * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(d2) + eps);
+        bool far = q < w.theta;
+        if (__any(__builtin_fabsf(q - w.theta) <= vote_margin))
+            far = (a.w / (__builtin_sqrtf(d2) + eps)) < w.theta;
+        const unsigned long long fm = __ballot(far || !live);
+        const bool all_far = ((fm >> (slot * 8)) & 0xFFull) == 0xFFull;
+        const bool massive = act && a.z != 0.0f;
+        accept = massive && (b.x < 0 || all_far);
+        open = massive && !accept;
+    };
+
+    // pass 1 below `root`: accepted (key, node) pairs into S.akey/S.anode; false when the lists overflowed
+    auto pass1 = [&](int root, int rdepth, int& na, unsigned& tv) -> bool {
+        bool first_iter = true, overflow = false;
+        int sp = 1;
+        na = 0; tv = 0;
+        if (lane == 0) { S.pnode[0] = root; S.pkey[0] = 1ull; }
+        bh_wave_sync();
         while (sp > 0 && !overflow) {
-#ifdef NBODY_WIDE_TIMING
-            ++iters;
-#endif
             int node[kWidePerSlot];
             unsigned long long key[kWidePerSlot];
             bool act[kWidePerSlot];
@@ -1217,8 +1241,8 @@ __global__ __launch_bounds__(64) void bh_walk_wide_kernel(const BhWalkArgs w)
             for (int u = 0; u < kWidePerSlot; ++u) {
                 const int e = sp - 1 - (u * 8 + slot);
                 act[u] = u * 8 + slot < take;
-                node[u] = act[u] ? pnode[e] : 0;
-                key[u] = act[u] ? pkey[e] : 1ull;
+                node[u] = act[u] ? S.pnode[e] : 0;
+                key[u] = act[u] ? S.pkey[e] : 1ull;
             }
             sp -= take;
             tv += (unsigned)take;
@@ -1226,118 +1250,227 @@ __global__ __launch_bounds__(64) void bh_walk_wide_kernel(const BhWalkArgs w)
             int2 b[kWidePerSlot];
 #pragma unroll
             for (int u = 0; u < kWidePerSlot; ++u) { a[u] = w.A[node[u]]; b[u] = w.B[node[u]]; }
-            __syncthreads();                              // every lane has read its entries before anyone overwrites them
+            bh_wave_sync();                               // every lane has read its entries before anyone overwrites them
 #pragma unroll
             for (int u = 0; u < kWidePerSlot; ++u) {
-                const float dx = a[u].x - xi, dy = a[u].y - yi;               // benchmark.cpp:254-255
-                const float d2 = __builtin_fmaf(dx, dx, dy * dy);
-                // The vote is a boolean: the hardware's 1-ulp sqrt/rcp decide it unless the ratio is within 4e-6
-                // (relative, > 10x their error bound) of theta, in which case the wave redoes the node with the IEEE
-                // expressions of benchmark.cpp:256-262 — same decisions as the oracle, a fifth of the instructions.
-                const float q = a[u].w * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(d2) + eps);
-                bool far = q < w.theta;
-                if (__any(__builtin_fabsf(q - w.theta) <= vote_margin))
-                    far = (a[u].w / (__builtin_sqrtf(d2) + eps)) < w.theta;
-                const unsigned long long fm = __ballot(far || !live);
-                const bool all_far = ((fm >> (slot * 8)) & 0xFFull) == 0xFFull;
-                const bool massive = act[u] && a[u].z != 0.0f;                 // :248
-                const bool accept = massive && (b[u].x < 0 || all_far);        // :266
-                const bool open = massive && !accept;
+                bool accept, open;
+                vote(a[u], b[u], act[u], accept, open);
                 const unsigned long long am = __ballot(accept && t == 0);
                 const int apos = na + __popcll(am & below_me);
                 if (accept && t == 0 && apos < kAcc) {
-                    akey[apos] = key[u] << (__builtin_clzll(key[u]) - 1);      // left-aligned: sentinel at bit 62
-                    anode[apos] = node[u];
+                    S.akey[apos] = key[u] << (__builtin_clzll(key[u]) - 1);    // left-aligned: sentinel at bit 62
+                    S.anode[apos] = node[u];
                 }
                 na += __popcll(am);
                 const unsigned long long om = __ballot(open && t == 0);
                 const int base = sp + 4 * __popcll(om & below_slot);
                 if (open && t < 4 && base + t < kStk) {
-                    pnode[base + t] = b[u].x + t;                              // children 0..3 (:272-274)
-                    pkey[base + t] = (key[u] << 2) | (unsigned long long)(3 - t);   // popped 3 first (:244)
+                    S.pnode[base + t] = b[u].x + t;                            // children 0..3 (:272-274)
+                    S.pkey[base + t] = (key[u] << 2) | (unsigned long long)(3 - t);   // popped 3 first (:244)
                 }
                 sp += 4 * __popcll(om);
             }
             overflow = sp > kStk || na > kAcc || (first_iter && rdepth < presplit && sp > 0);
             first_iter = false;
-            __syncthreads();
+            bh_wave_sync();
         }
-        if (overflow) {
-            // `root` was opened (its lists grew): count its visit and walk its four children one by one, 3 first
-            visits += 1;
-            const int cb = w.B[root].x;
-            if (lane < 4) { tasks[ntask + lane] = cb + lane; tdepth[ntask + lane] = (unsigned char)(rdepth + 1); }
-            ntask += 4;
-            __syncthreads();
-            continue;
+        return !overflow;
+    };
+
+    auto sort_list = [&](int na) {
+        if (na <= 1) return;
+        int P = 64;
+        while (P < na) P <<= 1;
+        for (int e = na + lane; e < P; e += 64) S.akey[e] = ~0ull;
+        bh_wave_sync();
+        if (P <= 64) bh_wide_sort<1>(S.akey, S.anode, lane);
+        else if (P <= 128) bh_wide_sort<2>(S.akey, S.anode, lane);
+        else bh_wide_sort<4>(S.akey, S.anode, lane);
+        bh_wave_sync();
+    };
+
+    // node kernel (benchmark.cpp:188-225): the term of one accepted node for this lane's target
+    auto term = [&](const float4& a, const int2& b, float& tx, float& ty) {
+        const float dx = a.x - xi, dy = a.y - yi;
+        const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+        float d, inv, f;
+        if constexpr (kFast) {
+            d = __builtin_amdgcn_sqrtf(d2);
+            inv = __builtin_amdgcn_rcpf(d + eps);
+            const float sd = __builtin_fmaxf(d, ri);
+            f = a.z * __builtin_amdgcn_rcpf(__builtin_fmaf(sd, sd, soft2));
+        } else {
+            d = __builtin_sqrtf(d2);
+            const float sd = __builtin_fmaxf(d, ri);                   // :201-202
+            f = a.z / __builtin_fmaf(sd, sd, soft2);                   // :203-209
+            inv = 1.0f / (d + eps);                                    // :212-213
         }
-        visits += tv;
-        accepts += (unsigned)na;
-        WIDE_TICK(tk1);
-        // ---- sort the accepted nodes into the reference's visiting order ----
-        if (na > 1) {
-            int P = 64;
-            while (P < na) P <<= 1;
-            for (int e = na + lane; e < P; e += 64) akey[e] = ~0ull;
-            __syncthreads();
-            if (P <= 64) bh_wide_sort<1>(akey, anode, lane);
-            else if (P <= 128) bh_wide_sort<2>(akey, anode, lane);
-            else if (P <= 256) bh_wide_sort<4>(akey, anode, lane);
-            else if (kAcc <= 512 || P <= 512) bh_wide_sort<8>(akey, anode, lane);
-            else if constexpr (kAcc > 512) bh_wide_sort<16>(akey, anode, lane);
-            __syncthreads();
-        }
-        WIDE_TICK(tk2);
-        // ---- pass 2: node kernel in that order, 8 * kWideRound nodes per round ----
+        const bool self = b.y == i;                                    // :197-198
+        tx = self ? 0.0f : (dx * inv) * f;
+        ty = self ? 0.0f : (dy * inv) * f;
+    };
+
+    // pass 2 over the sorted list from entry `c_begin` on: every lane adds its target's terms in list order
+    auto pass2 = [&](int c_begin, int na) {
         constexpr int kRound = 8 * kWideRound;
         float4 a[kWideRound];
         int2 b[kWideRound];
 #pragma unroll
         for (int u = 0; u < kWideRound; ++u) {
-            const int nd = u * 8 + slot < na ? anode[u * 8 + slot] : 0;
+            const int e = c_begin + u * 8 + slot;
+            const int nd = e < na ? S.anode[e] : 0;
             a[u] = w.A[nd]; b[u] = w.B[nd];
         }
-        for (int c0 = 0; c0 < na; c0 += kRound) {
+        for (int c0 = c_begin; c0 < na; c0 += kRound) {
             float4 an[kWideRound];
             int2 bn[kWideRound];
 #pragma unroll
-            for (int u = 0; u < kWideRound; ++u) {                             // next round's records are requested
-                const int e = c0 + kRound + u * 8 + slot;                      // before this round's arithmetic
-                const int nd = e < na ? anode[e] : 0;
+            for (int u = 0; u < kWideRound; ++u) {
+                const int e = c0 + kRound + u * 8 + slot;
+                const int nd = e < na ? S.anode[e] : 0;
                 an[u] = w.A[nd]; bn[u] = w.B[nd];
             }
 #pragma unroll
             for (int u = 0; u < kWideRound; ++u) {
-                const float dx = a[u].x - xi, dy = a[u].y - yi;
-                const float d2 = __builtin_fmaf(dx, dx, dy * dy);
-                float d, inv, f;
-                if constexpr (kFast) {
-                    d = __builtin_amdgcn_sqrtf(d2);
-                    inv = __builtin_amdgcn_rcpf(d + eps);
-                    const float sd = __builtin_fmaxf(d, ri);
-                    f = a[u].z * __builtin_amdgcn_rcpf(__builtin_fmaf(sd, sd, soft2));
-                } else {
-                    d = __builtin_sqrtf(d2);
-                    const float sd = __builtin_fmaxf(d, ri);                   // :201-202
-                    f = a[u].z / __builtin_fmaf(sd, sd, soft2);                // :203-209
-                    inv = 1.0f / (d + eps);                                    // :212-213
-                }
-                const bool self = b[u].y == i;                                 // :197-198
-                termx[u * 8 + slot][t] = self ? 0.0f : (dx * inv) * f;
-                termy[u * 8 + slot][t] = self ? 0.0f : (dy * inv) * f;
+                float tx, ty;
+                term(a[u], b[u], tx, ty);
+                S.termx[u * 8 + slot][t] = tx;
+                S.termy[u * 8 + slot][t] = ty;
             }
-            __syncthreads();
+            bh_wave_sync();
             const int nv = na - c0 < kRound ? na - c0 : kRound;
-            for (int u = 0; u < nv; ++u) { ax = ax + termx[u][t]; ay = ay + termy[u][t]; }
-            __syncthreads();
+            float vx[kRound], vy[kRound];                  // all reads in flight, then the adds in order
+#pragma unroll
+            for (int u = 0; u < kRound; ++u) { vx[u] = S.termx[u][t]; vy[u] = S.termy[u][t]; }
+#pragma unroll
+            for (int u = 0; u < kRound; ++u)
+                if (u < nv) { ax = ax + vx[u]; ay = ay + vy[u]; }
+            bh_wave_sync();
 #pragma unroll
             for (int u = 0; u < kWideRound; ++u) { a[u] = an[u]; b[u] = bn[u]; }
         }
-        WIDE_TICK(tk3);
-    }
+    };
+
+    // task loop: a traversal that outgrows the lists is split into its four children, walked one by one
+    auto run_tasks = [&](int root, int rdepth) {
+        int ntask = 1;
+        if (lane == 0) { S.tasks[0] = root; S.tdepth[0] = (unsigned char)rdepth; }
+        bh_wave_sync();
+        while (ntask > 0) {
+            const int r = S.tasks[--ntask];
+            const int rd = S.tdepth[ntask];
+            int na; unsigned tv;
+            if (!pass1(r, rd, na, tv)) {
+                visits += 1;                               // `r` was opened: its visit, then its children 3 first
+                const int cb = w.B[r].x;
+                if (lane < 4) { S.tasks[ntask + lane] = cb + lane; S.tdepth[ntask + lane] = (unsigned char)(rd + 1); }
+                ntask += 4;
+                bh_wave_sync();
+                continue;
+            }
+            visits += tv;
+            accepts += (unsigned)na;
+            sort_list(na);
+            pass2(0, na);
+        }
+    };
+
+    // does the group open the root?  Every wave takes the vote itself (same data, same answer: workgroup-uniform).
+    const float4 a0 = w.A[0];
+    const int2 b0 = w.B[0];
+    bool root_accept, root_open;
+    vote(a0, b0, true, root_accept, root_open);
+    root_open = __any(root_open && slot == 0);             // (identical in every slot; made wave-uniform for the compiler)
+    if (!root_open) {
+        if (wv != 0) return;
+        run_tasks(0, 0);                                   // a leaf, an accepted or a massless root: one visit, wave 0 alone
+    } else {
+        // phase A, all four waves: traversal + sort of root child 3 - wv, and the terms of its first 8 * kHeld accepted
+        // nodes, kept in registers (kHeld per lane: node r * 8 + slot for target t) — everything that does not depend
+        // on the sums of the subtrees before it
+        constexpr int kHeld = 12;
+        const int my_root = b0.x + (3 - wv);
+        int na; unsigned tv;
 #ifdef NBODY_WIDE_TIMING
-    if (t == 0) { ax = (float)tk1; ay = (float)tk2; } else if (t == 1) { ax = (float)tk3; ay = (float)iters; }
+        const unsigned long long q0 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long q1 = 0, q2 = 0, q4 = 0, q5 = 0;
 #endif
+        const bool fits = pass1(my_root, 1, na, tv);
+#ifdef NBODY_WIDE_TIMING
+        q1 = __builtin_amdgcn_s_memrealtime();
+#endif
+        float hx[kHeld], hy[kHeld];
+#pragma unroll
+        for (int r = 0; r < kHeld; ++r) { hx[r] = 0.0f; hy[r] = 0.0f; }
+        if (fits) {
+            sort_list(na);
+#pragma unroll
+            for (int r0 = 0; r0 < kHeld; r0 += 4) {
+                if (r0 * 8 < na) {                         // wave-uniform
+                    float4 a[4];
+                    int2 b[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = (r0 + u) * 8 + slot;
+                        const int nd = e < na ? S.anode[e] : 0;
+                        a[u] = w.A[nd]; b[u] = w.B[nd];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) term(a[u], b[u], hx[r0 + u], hy[r0 + u]);
+                }
+            }
+        }
+#ifdef NBODY_WIDE_TIMING
+        q2 = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (threadIdx.x == 0) { cnt_v = 1; cnt_a = 0; }    // the root's own visit
+        __syncthreads();
+        // phase B, one wave after the other in the reference's order: only the additions (and what did not fit above).
+        // Every wave passes four barriers: wv of them before its turn, 4 - wv after it.
+        for (int k = 0; k < wv; ++k) __syncthreads();
+#ifdef NBODY_WIDE_TIMING
+        q4 = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (wv > 0) { ax = accx[t]; ay = accy[t]; }
+        if (fits) {
+            visits = tv; accepts = (unsigned)na;
+#pragma unroll
+            for (int r = 0; r < kHeld; ++r) {
+                if (r * 8 < na) {                          // wave-uniform
+                    S.termx[slot][t] = hx[r]; S.termy[slot][t] = hy[r];
+                    bh_wave_sync();
+                    const int nv = na - r * 8 < 8 ? na - r * 8 : 8;
+                    float vx[8], vy[8];                    // all reads in flight, then the adds in order
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { vx[u] = S.termx[u][t]; vy[u] = S.termy[u][t]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (u < nv) { ax = ax + vx[u]; ay = ay + vy[u]; }
+                    bh_wave_sync();
+                }
+            }
+            if (na > 8 * kHeld) pass2(8 * kHeld, na);
+        } else {
+            run_tasks(my_root, 1);
+        }
+        if (slot == 0) { accx[t] = ax; accy[t] = ay; }
+        if (lane == 0) { cnt_v += visits; cnt_a += accepts; }
+#ifdef NBODY_WIDE_TIMING
+        q5 = __builtin_amdgcn_s_memrealtime();
+#endif
+        for (int k = wv; k < 4; ++k) __syncthreads();
+#ifdef NBODY_WIDE_TIMING      // developer build: 100 MHz ticks per phase instead of results, wave wv in bodies 2 wv, 2 wv + 1
+        if (slot == 0 && (t >> 1) == wv && live) {
+            const unsigned long long q6 = __builtin_amdgcn_s_memrealtime();
+            w.ax[i] = (t & 1) ? (float)(q5 - q4) : (float)(q1 - q0);
+            w.ay[i] = (t & 1) ? (float)(q6 - q0) : (float)(q2 - q1);
+        }
+        if (wv == 3 && lane == 0) { w.grp_visits[(w.i_begin >> 3) + blockIdx.x] = (int)cnt_v; w.grp_accepts[(w.i_begin >> 3) + blockIdx.x] = (int)cnt_a; }
+        return;
+#endif
+        if (wv != 3) return;
+        visits = cnt_v; accepts = cnt_a;
+    }
     if (live && slot == 0) {
         w.ax[i] = ax;
         w.ay[i] = ay;

@@ -57,7 +57,7 @@ struct Profiler {
 constexpr int kMaxSlices = 64;
 constexpr int kBhClimbMax = 1 << 21;         // bodies: up to here the centre-of-mass pass is ONE launch (bh_com_climb_kernel)
 constexpr float kBhSortedThetaScale = 0.6f;     // tools/bh_sorted_scale.py, profiles/r2_bh_sorted_scale.txt
-constexpr int kBhWideMaxGroups = 4096;      // <= 32 768 targets: the walk takes one wave per group (measured crossover)
+constexpr int kBhQuadMaxGroups = 6144;      // <= 49 152 targets: four waves per group (bh_walk_quad_kernel; measured crossover)
 constexpr size_t kMaxEventsPerClass = 4096;
 
 }  // namespace
@@ -345,23 +345,16 @@ int enqueue_bh_walk(nbody_ctx* ctx, int advance)
     EventPair* ep;
     int rc = profile_begin(ctx, 0, &ep);
     if (rc) return rc;
-    // Few groups: one wave per group, all 64 lanes on it (bh_walk_wide_kernel); many: 8 groups per wave.
+    // Up to ~50 000 targets a group gets a workgroup of four waves (bh_walk_quad_kernel), above that 8 groups share a
+    // wave (bh_walk_kernel).  Measured walk us, quad / 8-per-wave (tools/bh_steady.py): N = 10 000 67 / 235,
+    // 32 768 186 / 330, 49 152 292 / 363, 65 536 369 / 374, 131 072 698 / 436.
     const int groups = (nt + 7) / 8;
-    bool wide = groups <= kBhWideMaxGroups;
-    if (const char* e = std::getenv("NBODY_BH_WIDE")) wide = e[0] == '1';       // developer A/B switch
-    if (wide) {
+    int quad_max = kBhQuadMaxGroups;
+    if (const char* e = std::getenv("NBODY_BH_QUAD_MAX")) quad_max = std::atoi(e);              // developer/test switch
+    if (groups <= quad_max) {
         w.lanes_used = 8;
-        // measured (tools/bh_steady.py, walk us at N = 10 000 / 20 000 / 32 768): big lists 101 / 183 / 217, small lists
-        // 97 / 160 / 236 — more resident waves help until the 512-entry accept list starts to overflow
-        bool small_lists = groups <= 3072;
-        if (const char* e = std::getenv("NBODY_BH_WIDE_LISTS")) small_lists = e[0] == 's';     // developer A/B switch
-        if (small_lists) {
-            if (ctx->cfg.bh_fast_math) bh_walk_wide_kernel<true, 512, 256><<<dim3(groups), dim3(64), 0, ctx->stream>>>(w);
-            else                       bh_walk_wide_kernel<false, 512, 256><<<dim3(groups), dim3(64), 0, ctx->stream>>>(w);
-        } else {
-            if (ctx->cfg.bh_fast_math) bh_walk_wide_kernel<true, 1024, 512><<<dim3(groups), dim3(64), 0, ctx->stream>>>(w);
-            else                       bh_walk_wide_kernel<false, 1024, 512><<<dim3(groups), dim3(64), 0, ctx->stream>>>(w);
-        }
+        if (ctx->cfg.bh_fast_math) bh_walk_quad_kernel<true><<<dim3(groups), dim3(256), 0, ctx->stream>>>(w);
+        else                       bh_walk_quad_kernel<false><<<dim3(groups), dim3(256), 0, ctx->stream>>>(w);
     } else {
         w.lanes_used = 8 * bh_walk_groups_per_wave(nt);
         const int per_block = (kBhBlock / 64) * w.lanes_used;      // targets per workgroup

@@ -208,31 +208,41 @@ def test_distinct_bodies_closer_than_the_finest_cell_vs_the_references_own_tree(
     assert np.all(d <= 1.05 * 1000.0 / 64.0)                                  # at most their mutual force m/R^2
 
 
-@pytest.mark.parametrize("n,theta,fast", [(10000, 1.0, False), (10000, 0.5, True), (4099, 0.15, False), (65536, 1.0, False)])
-def test_wide_walk_equals_the_group_per_8_lanes_walk(nb, O, n, theta, fast, monkeypatch):
-    """Two walk kernels, one result.  Below 32 768 targets the walk takes one wave per group (bh_walk_wide_kernel:
-    order-free parallel traversal, sort into the reference's visiting order, in-order accumulation), above it 8 groups
-    per wave (bh_walk_kernel: the reference's DFS as is).  NBODY_BH_WIDE forces either one: accelerations, totals and
-    per-group counters must be bit-identical, and equal to the oracle's.  theta = 0.15 overflows the wide kernel's
-    LDS lists (> 1024 accepted nodes per group), so its task splitting is exercised too."""
+@pytest.mark.parametrize("n,theta,fast", [(10000, 1.0, False), (10000, 0.5, True), (4099, 0.15, False), (65536, 1.0, False),
+                                          (1003, 1.0, False)])
+def test_two_walk_kernels_one_result(nb, O, n, theta, fast, monkeypatch):
+    """Two walk kernels, one result.  Up to 49 152 targets a group gets a workgroup of four waves (bh_walk_quad_kernel:
+    the root's four subtrees traversed in parallel and order-free, their accepted nodes sorted into the reference's
+    visiting order, node kernel and additions subtree after subtree in that order), above that 8 groups share a wave
+    (bh_walk_kernel: the reference's DFS as is).  NBODY_BH_QUAD_MAX forces either at any size: accelerations, totals and
+    per-group counters must be bit-identical, and equal to the oracle's.  theta = 0.15 overflows the parallel kernel's
+    LDS lists (> 1024 accepted nodes per group), so its task splitting is exercised too; the second pass over each
+    kernel runs with the accept counts of the first as its splitting hint."""
     b = O.init_disc(n, seed=2024)
     out = {}
-    for wide in ("0", "1"):
-        monkeypatch.setenv("NBODY_BH_WIDE", wide)
-        ax, ay, _, _, cnt = gpu_bh(nb, b, theta=theta, bh_fast_math=fast, want_groups=True)
-        out[wide] = (ax, ay, cnt)
-    monkeypatch.delenv("NBODY_BH_WIDE")
-    (ax0, ay0, c0), (ax1, ay1, c1) = out["0"], out["1"]
-    assert np.array_equal(ax0, ax1) and np.array_equal(ay0, ay1)
-    assert (c0["visits"], c0["accepts"]) == (c1["visits"], c1["accepts"])
-    assert np.array_equal(c0["groups"][0], c1["groups"][0]) and np.array_equal(c0["groups"][1], c1["groups"][1])
+    for name, quad in (("dfs", "0"), ("quad", "100000000")):
+        monkeypatch.setenv("NBODY_BH_QUAD_MAX", quad)
+        with nb.NBodySim(n, theta=theta, useBarnesHut=True, bh_fast_math=fast) as sim:
+            sim.upload(*b.arrays())
+            for _ in range(2):                                           # cold hint, then the previous walk's
+                sim.compute_accel().sync()
+                ax, ay = sim.accel()
+                cnt = dict(sim.bh_counters(), groups=sim.bh_group_counters())
+                out.setdefault(name, []).append((ax, ay, cnt))
+    monkeypatch.delenv("NBODY_BH_QUAD_MAX")
+    ax0, ay0, c0 = out["dfs"][0]
+    for name in ("dfs", "quad"):
+        for ax1, ay1, c1 in out[name]:
+            assert np.array_equal(ax0, ax1) and np.array_equal(ay0, ay1), name
+            assert (c0["visits"], c0["accepts"]) == (c1["visits"], c1["accepts"]), name
+            assert np.array_equal(c0["groups"][0], c1["groups"][0]) and np.array_equal(c0["groups"][1], c1["groups"][1]), name
     ot = O.Tree(n).build(b, 400.0)
     ox, oy, ocnt = ot.accel(b, theta)
-    assert (c1["visits"], c1["accepts"]) == (ocnt["visits"], ocnt["accepts"])
+    assert (c0["visits"], c0["accepts"]) == (ocnt["visits"], ocnt["accepts"])
     if theta == 0.15:
-        assert c1["groups"][1].max() > 1024                               # the lists did overflow
+        assert c0["groups"][1].max() > 1024                               # the lists did overflow
     if not fast:
-        assert np.array_equal(ax1, ox.astype(np.float32)) and np.array_equal(ay1, oy.astype(np.float32))
+        assert np.array_equal(ax0, ox.astype(np.float32)) and np.array_equal(ay0, oy.astype(np.float32))
 
 
 @pytest.mark.parametrize("per_depth", [False, True])
