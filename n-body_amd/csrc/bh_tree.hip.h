@@ -171,12 +171,15 @@ __device__ __forceinline__ int bh_valid_total(const BhCounters* __restrict__ ctr
 // that arrives last at its i-tile (count-off as in bh_com_climb_kernel: adds acknowledged, then one atomic on the
 // tile's counter) reads the complete ranks with device-scope loads, scatters the tile and leaves rank[] and the
 // counter zero for the next build.
+__device__ __forceinline__ int bh_first_tie(uint16_t rec);
 constexpr int kBhRankChunk = 512;                   // keys staged in LDS per round
 constexpr int kBhRankSortMax = 12288;               // bodies (measured: -14 us at 10 000, +-0 at 16 384, +54 us at 32 768)
 
 __global__ __launch_bounds__(kBhBlock) void bh_ranksort_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals, int n,
                                                                int j_per_slice, int* rank, int* done,
-                                                               uint64_t* __restrict__ keys_sorted, int* __restrict__ vals_sorted)
+                                                               uint64_t* __restrict__ keys_sorted, int* __restrict__ vals_sorted,
+                                                               const uint16_t* __restrict__ tie,
+                                                               unsigned char* __restrict__ tie_first_sorted)
 {
     __shared__ __align__(16) uint64_t tile[kBhRankChunk];
     __shared__ int last;
@@ -209,7 +212,14 @@ __global__ __launch_bounds__(kBhBlock) void bh_ranksort_kernel(const uint64_t* _
     if (!last) return;
     if (live) {
         const int r = __hip_atomic_load(&rank[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)r < (unsigned)n) { keys_sorted[r] = ki; vals_sorted[r] = vals[i]; }
+        const int body = vals[i];
+        if ((unsigned)r < (unsigned)n) {
+            keys_sorted[r] = ki;
+            vals_sorted[r] = body;
+            // first level at which the body sits on a split line, in sorted order: the preparation kernel reads it next
+            // to the keys instead of gathering it through vals_sorted
+            tie_first_sorted[r] = (unsigned char)bh_first_tie(tie[body]);
+        }
         rank[i] = 0;
     }
     if (tid == 0) done[blockIdx.x] = 0;
@@ -560,7 +570,8 @@ __global__ __launch_bounds__(kBhFixBlock) void bh_prep_small_kernel(const uint64
                                                                     BhTies T, int n, uint64_t* __restrict__ gkeys_sorted,
                                                                     int* __restrict__ gvals_sorted, uint64_t* __restrict__ okeys,
                                                                     int* __restrict__ ovals, int* __restrict__ cnt,
-                                                                    int* __restrict__ base, int* __restrict__ owner, int cap_internal)
+                                                                    int* __restrict__ base, int* __restrict__ owner, int cap_internal,
+                                                                    const unsigned char* __restrict__ tie_first_sorted)
 {
     __shared__ uint64_t sk[kBhSmallGhosts];
     __shared__ int sv[kBhSmallGhosts];
@@ -568,18 +579,61 @@ __global__ __launch_bounds__(kBhFixBlock) void bh_prep_small_kernel(const uint64
     const int tid = threadIdx.x;
     BH_DBG_TICK(ctr, 0);
     const int M0 = bh_valid_total(ctr);                            // counted by bh_keys_kernel
-    // 2b. second instances of bodies on split lines.  All but a few bodies per million have no tie on their path:
-    // the two dependent loads that say so (body of the sorted slot, its tie record) are issued eight at a time.
-    constexpr int kBatch = 16;
-    for (int i0 = tid; i0 < M0; i0 += kBatch * kBhFixBlock) {
-        int bb[kBatch], first[kBatch];
+    // Every wave takes one contiguous sixteenth of the sorted instances, 64 consecutive ones per round, 10 rounds of
+    // loads in flight (the neighbours' keys come by shuffle; the two at the ends of a round are loaded).
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int kRounds = 10;
+    // one round of a pass: this lane's key and the common-prefix lengths with its neighbours
+    auto load_round = [&](const uint64_t* mk, int M, int r0, int w1, uint64_t& kc, uint64_t& kedge) {
+        const int i = r0 + lane;
+        kc = i < w1 ? mk[i] : 0;
+        const int j = lane == 0 ? r0 - 1 : r0 + 64;                // lane 0: the key before the round, lane 63: after
+        kedge = (lane == 0 || lane == 63) && j >= 0 && j < M ? mk[j] : 0;
+    };
+    auto cells_of = [&](int M, int r0, int w1, uint64_t kc, uint64_t kedge, int& lp, int& ln) -> int {
+        const int i = r0 + lane;
+        uint64_t kp = __shfl_up(kc, 1, 64), kn = __shfl_down(kc, 1, 64);
+        if (lane == 0) kp = kedge;
+        if (lane == 63) kn = kedge;
+        lp = i > 0 && i < M ? bh_lcp_levels(kp, kc) : -1;
+        ln = i + 1 < M ? bh_lcp_levels(kc, kn) : -1;
+        return i < w1 && ln > lp ? ln - lp : 0;
+    };
+
+    // 2b. second instances of bodies on split lines, and — the same keys, the same prefix lengths — the number of cells
+    // each wave's primaries own (pass 0 of step 3, valid as it is when there turn out to be no second instances, i.e.
+    // nearly always).  A primary spawns instances only where it sits on a split line ABOVE its leaf: first tie level <
+    // leaf depth = 1 + max(lcp with either neighbour).  Far down, where cells are narrower than a float ulp, almost
+    // every body "sits on a line", so the test against the leaf depth is what makes the expensive path rare.
+    const int per0 = (((M0 + kBhFixBlock / 64 - 1) / (kBhFixBlock / 64)) + 63) & ~63;
+    const int a0 = wave * per0, a1 = a0 + per0 < M0 ? a0 + per0 : M0;
+    int total = 0;
+    for (int i0 = a0; i0 < a1; i0 += kRounds * 64) {
+        uint64_t kc[kRounds], ke[kRounds];
+        int first[kRounds];
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u) { const int i = i0 + u * kBhFixBlock; bb[u] = i < M0 ? vals[i] : -1; }
+        for (int u = 0; u < kRounds; ++u) {
+            load_round(keys, M0, i0 + u * 64, a1, kc[u], ke[u]);
+            const int i = i0 + u * 64 + lane;
+            first[u] = i < a1 ? (tie_first_sorted ? (int)tie_first_sorted[i] : vals[i]) : kBhLevels;
+        }
+        if (tie_first_sorted == nullptr) {
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u) first[u] = bb[u] >= 0 ? bh_first_tie(tie[bb[u]]) : kBhLevels;
+            for (int u = 0; u < kRounds; ++u)
+                if (i0 + u * 64 + lane < a1) first[u] = bh_first_tie(tie[first[u]]);
+        }
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u)
-            if (first[u] != kBhLevels) bh_ties_one(i0 + u * kBhFixBlock, M0, keys, vals, px, py, tie, ctr, T);
+        for (int u = 0; u < kRounds; ++u) {
+            if (i0 + u * 64 < a1) {                                // wave-uniform
+                int lp, ln;
+                total += cells_of(M0, i0 + u * 64, a1, kc[u], ke[u], lp, ln);
+                const int leaf_depth = 1 + (lp > ln ? lp : ln);
+                // the fixed-point phase raises T.pld of ANY primary with a tie record when a second instance deepens
+                // its leaf: it has to hold the leaf depth for all of them, not only for those that spawn now
+                if (first[u] != kBhLevels) T.pld[i0 + u * 64 + lane] = leaf_depth;
+                if (first[u] < leaf_depth) bh_ties_one(i0 + u * 64 + lane, M0, keys, vals, px, py, tie, ctr, T);
+            }
+        }
     }
     __syncthreads();            // one workgroup = one CU = one L1: a barrier is all the ordering the phases need
     BH_DBG_TICK(ctr, 1);
@@ -617,56 +671,53 @@ __global__ __launch_bounds__(kBhFixBlock) void bh_prep_small_kernel(const uint64
     const int M = M0 + G;
     BH_DBG_TICK(ctr, 3);
     if (tid == 0) ctr->valid = M;
-    // 3. cells owned by each instance, their exclusive scan (= cell ids) and 4a. the owner of every cell, in rounds
-    // of 1024 consecutive instances: coalesced loads (8 rounds in flight per thread), a shuffle scan inside each
-    // wave, the 16 wave totals through LDS, coalesced stores.
-    const int lane = tid & 63, wave = tid >> 6;
-    int running = 0;                                               // cells before this round (block-uniform)
-    constexpr int kRounds = 8;                                     // 3 keys x 8 rounds in flight: 48 VGPRs
-    for (int i0 = 0; i0 < M; i0 += kRounds * kBhFixBlock) {
-        uint64_t kp[kRounds], kc[kRounds], kn[kRounds];
+    // 3. cells owned by each instance, their exclusive scan (= cell ids) and 4a. the owner of every cell: a wave's
+    // total first (pass 0: done above unless the merge changed the array), then — one LDS barrier later, when it knows
+    // the totals of the waves before it — the scan itself (shuffle scan per round, running offset in a register) and
+    // the stores.  (Round 2's first version synchronised all 16 waves twice per 1024 instances.)
+    const int per = (((M + kBhFixBlock / 64 - 1) / (kBhFixBlock / 64)) + 63) & ~63;
+    const int w0 = wave * per, w1 = w0 + per < M ? w0 + per : M;
+    if (G > 0) {
+        total = 0;
+        for (int i0 = w0; i0 < w1; i0 += kRounds * 64) {
+            uint64_t kc[kRounds], ke[kRounds];
 #pragma unroll
-        for (int u = 0; u < kRounds; ++u) {
-            const int i = i0 + u * kBhFixBlock + tid;
-            kc[u] = i < M ? mk[i] : 0;
-            kp[u] = i < M && i > 0 ? mk[i - 1] : 0;
-            kn[u] = i + 1 < M ? mk[i + 1] : 0;
+            for (int u = 0; u < kRounds; ++u) load_round(mk, M, i0 + u * 64, w1, kc[u], ke[u]);
+#pragma unroll
+            for (int u = 0; u < kRounds; ++u)
+                if (i0 + u * 64 < w1) { int lp, ln; total += cells_of(M, i0 + u * 64, w1, kc[u], ke[u], lp, ln); }
         }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+    if (lane == 0) part[wave] = total;
+    __syncthreads();
+    int running = 0;
+    for (int w2 = 0; w2 < wave; ++w2) running += part[w2];
+    for (int i0 = w0; i0 < w1; i0 += kRounds * 64) {
+        uint64_t kc[kRounds], ke[kRounds];
+#pragma unroll
+        for (int u = 0; u < kRounds; ++u) load_round(mk, M, i0 + u * 64, w1, kc[u], ke[u]);
 #pragma unroll
         for (int u = 0; u < kRounds; ++u) {
-            const int r0 = i0 + u * kBhFixBlock;
-            if (r0 < M) {                                          // block-uniform
-                const int i = r0 + tid;
-                int c = 0;
-                if (i < M) {
-                    const int lp = i > 0 ? bh_lcp_levels(kp[u], kc[u]) : -1;
-                    const int ln = i + 1 < M ? bh_lcp_levels(kc[u], kn[u]) : -1;
-                    c = ln > lp ? ln - lp : 0;
-                }
+            if (i0 + u * 64 < w1) {                                // wave-uniform
+                int lp, ln;
+                const int c = cells_of(M, i0 + u * 64, w1, kc[u], ke[u], lp, ln);
                 int incl = c;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
                     const int v = __shfl_up(incl, off, 64);
                     if (lane >= off) incl += v;
                 }
-                if (lane == 63) part[wave] = incl;
-                bh_lds_barrier();
-                int before = running, total = 0;
-#pragma unroll
-                for (int w2 = 0; w2 < kBhFixBlock / 64; ++w2) {
-                    const int pw = part[w2];
-                    before += w2 < wave ? pw : 0;
-                    total += pw;
-                }
-                bh_lds_barrier();                                  // part[] is read before the next round rewrites it
-                running += total;
-                if (i < M) {
-                    const int first = before + incl - c;
+                const int i = i0 + u * 64 + lane;
+                if (i < w1) {
+                    const int first = running + incl - c;
                     cnt[i] = c;
                     base[i] = first;
                     for (int k = 0; k < c; ++k)
                         if (first + k < cap_internal) owner[first + k] = i;
                 }
+                running += __shfl(incl, 63, 64);
             }
         }
     }

@@ -123,7 +123,8 @@ struct nbody_ctx {
         int* own_order = nullptr;
         void* own_sort_tmp = nullptr;
         size_t own_sort_bytes = 0;
-        int *rank = nullptr, *rank_done = nullptr;   // small-N rank sort: partial ranks [n], per-tile arrival counters
+        int *rank = nullptr, *rank_done = nullptr;   // small-N rank sort: partial ranks [n], per-tile arrival counters,
+        unsigned char* tie_first_sorted = nullptr;   //   first split-line level of each body, in sorted order [n]
         void *sort_tmp = nullptr, *scan_tmp = nullptr;
         size_t sort_bytes = 0, scan_bytes = 0;
         int64_t node_cap = 0;
@@ -259,13 +260,15 @@ int enqueue_bh_build(nbody_ctx* ctx)
     bh_keys_kernel<<<grid_n, blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr, ctx->cfg.spread, adaptive ? 0 : 1, b.keys, b.vals, b.tie,
                                           b.gkeys, b.gvals, b.gcap, b.tie_table, b.tie_table_size, fused ? 1 : 0);
     const char* rank_env = std::getenv("NBODY_BH_RANKSORT_MAX");         // developer/test switch
-    if (fused && n <= (rank_env ? std::atoi(rank_env) : kBhRankSortMax)) {
+    const bool ranked = fused && n <= (rank_env ? std::atoi(rank_env) : kBhRankSortMax);
+    if (ranked) {
         // small N: rank by brute-force counting, one launch.  ~1024 workgroups: i-tiles of 256 x j-slices
         const int tiles = (int)grid_n.x;
         int slices = 1024 / tiles < 1 ? 1 : (1024 / tiles > 64 ? 64 : 1024 / tiles);
         const int per = ((n + slices - 1) / slices + kBhRankChunk - 1) / kBhRankChunk * kBhRankChunk;
         slices = (n + per - 1) / per;
-        bh_ranksort_kernel<<<dim3(grid_n.x, slices), blk, 0, s>>>(b.keys, b.vals, n, per, b.rank, b.rank_done, b.keys_sorted, b.vals_sorted);
+        bh_ranksort_kernel<<<dim3(grid_n.x, slices), blk, 0, s>>>(b.keys, b.vals, n, per, b.rank, b.rank_done, b.keys_sorted, b.vals_sorted,
+                                                                  b.tie, b.tie_first_sorted);
     } else {
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, b.keys, b.keys_sorted, b.vals, b.vals_sorted, n,
                                                    0, 64, s));
@@ -276,7 +279,7 @@ int enqueue_bh_build(nbody_ctx* ctx)
         // small N: valid count, split-line instances, their sort, merge, cell count, scan and owners in one launch
         bh_prep_small_kernel<<<1, kBhFixBlock, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties, n,
                                                        b.gkeys_sorted, b.gvals_sorted, b.keys_merged, b.vals_merged, b.cnt, b.base,
-                                                       b.owner, b.tree.cap_internal);
+                                                       b.owner, b.tree.cap_internal, ranked ? b.tie_first_sorted : nullptr);
     } else {
         bh_valid_kernel<<<1, 64, 0, s>>>(b.keys_sorted, n, b.ctr);
         bh_ties_kernel<<<grid_n, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties);
@@ -549,6 +552,7 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
         if (n <= kBhRankSortMax) {                             // both stay zero between builds (the kernel re-zeroes them)
             HIP_TRY_C(hipMalloc((void**)&b.rank, sizeof(int) * (size_t)n));
             HIP_TRY_C(hipMalloc((void**)&b.rank_done, sizeof(int) * ((size_t)n / kBhBlock + 1)));
+            HIP_TRY_C(hipMalloc((void**)&b.tie_first_sorted, (size_t)n + 16));
             HIP_TRY_C(hipMemset(b.rank, 0, sizeof(int) * (size_t)n));
             HIP_TRY_C(hipMemset(b.rank_done, 0, sizeof(int) * ((size_t)n / kBhBlock + 1)));
         }
@@ -593,7 +597,7 @@ void nbody_destroy(nbody_ctx* ctx)
     {
         auto& b = ctx->bh;
         void* ptrs[] = {b.keys, b.keys_sorted, b.vals, b.vals_sorted, b.cnt, b.base, b.tree.A, b.tree.B,
-                        b.tree.depth, b.tree.self, b.tree.pend, b.rank, b.rank_done, b.ctr, b.tie, b.owner, b.gfx, b.gfy, b.gld, b.pld, b.glo, b.ghi, b.gpos, b.tie_table, b.sort_tmp, b.scan_tmp, b.gkeys, b.gkeys_sorted, b.gvals,
+                        b.tree.depth, b.tree.self, b.tree.pend, b.rank, b.rank_done, b.tie_first_sorted, b.ctr, b.tie, b.owner, b.gfx, b.gfy, b.gld, b.pld, b.glo, b.ghi, b.gpos, b.tie_table, b.sort_tmp, b.scan_tmp, b.gkeys, b.gkeys_sorted, b.gvals,
                         b.gvals_sorted, b.keys_merged, b.vals_merged, b.gsort_tmp, b.grp_visits, b.grp_accepts,
                         b.own_keys_sorted, b.own_order, b.own_sort_tmp};
         for (void* p : ptrs)
@@ -1062,11 +1066,8 @@ int nbody_bh_counters(nbody_ctx* ctx, int64_t out[2])
     out[1] = (int64_t)h.accepts;
 #ifdef NBODY_WIDE_TIMING
     if (std::getenv("NBODY_DEBUG")) {
-        std::fprintf(stderr, "[nbody] prep phases (us): valid+ties %.2f fixpoint %.2f ghosts/merge %.2f count %.2f scan %.2f write %.2f | "
-                             "com: sort-by-depth %.2f first fetches %.2f levels %.2f\n",
-                     (h.dbg[1] - h.dbg[0]) * 0.01, (h.dbg[2] - h.dbg[1]) * 0.01, (h.dbg[3] - h.dbg[2]) * 0.01, (h.dbg[4] - h.dbg[3]) * 0.01,
-                     (h.dbg[5] - h.dbg[4]) * 0.01, (h.dbg[6] - h.dbg[5]) * 0.01, (h.dbg[9] - h.dbg[8]) * 0.01, (h.dbg[10] - h.dbg[9]) * 0.01,
-                     (h.dbg[11] - h.dbg[10]) * 0.01);
+        std::fprintf(stderr, "[nbody] prep phases (us): valid+ties %.2f fixpoint %.2f ghosts/merge %.2f count+scan+owners %.2f\n",
+                     (h.dbg[1] - h.dbg[0]) * 0.01, (h.dbg[2] - h.dbg[1]) * 0.01, (h.dbg[3] - h.dbg[2]) * 0.01, (h.dbg[6] - h.dbg[3]) * 0.01);
     }
 #endif
     if (std::getenv("NBODY_DEBUG"))
