@@ -489,8 +489,18 @@ __device__ __forceinline__ void bh_merge_one(int t, const uint64_t* __restrict__
         const uint64_t k = gkeys[g];
         int lo = 0, hi = n;                                    // primaries with a key <= mine
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] <= k) lo = mid + 1; else hi = mid; }
-        okeys[g + lo] = k;
-        ovals[g + lo] = gvals[g];
+        // Second instances with EQUAL keys (bodies sharing a finest cell that sit on the same split lines) arrive from
+        // the device radix sort in the order in which the atomics of step 2b happened to append them.  Which body a
+        // shared leaf names — and so whose self term is masked — must not depend on that: within a run of equal keys
+        // the instances go out ordered by body, as the small build's LDS sort leaves them.  Runs are a few entries.
+        int g0 = g, before = 0;
+        const int body = gvals[g];
+        if (k != ~0ull) {                                      // (the padding behind the instances is one long run)
+            while (g0 > 0 && gkeys[g0 - 1] == k) --g0;
+            for (int j = g0; j < gcap && gkeys[j] == k; ++j) before += gvals[j] < body || (gvals[j] == body && j < g);
+        }
+        okeys[g0 + before + lo] = k;
+        ovals[g0 + before + lo] = body;
     }
 }
 
