@@ -367,7 +367,9 @@ def test_alternative_kernels_agree_on_adversarial_inputs(nb, O):
     """tools/bh_paths_soak.py: 60 random sizes (9 ... 300 000) and inputs (split-line lattices, clusters, bodies sharing
     a finest cell, out-of-box bodies; some stepped three times), each built and walked with the size's default kernels
     three times and with every alternative forced (device radix sort, separate preparation kernels, per-depth centre of
-    mass, 8-groups-per-wave walk): trees, per-group counters and accelerations bit-equal.  Round 2, seed 1: round 59
+    mass, 8-groups-per-wave walk): trees, per-group counters and accelerations bit-equal; unstepped inputs are also
+    walked shard by shard for a random number of ranks (both walk kernels) and in bh_sorted order (every alternative
+    against the default).  Round 2, seed 1: round 59
     (N = 40 000, two bodies sharing a finest cell AND sitting on a split line) named a different body in the shared
     leaf from run to run — second instances with equal keys went out in the arrival order of their atomics — until
     bh_merge_one ordered them by body."""

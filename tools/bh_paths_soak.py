@@ -16,10 +16,10 @@ from bh_stress import make
 ALT = {"NBODY_BH_NO_FUSE": "1", "NBODY_BH_RANKSORT_MAX": "0", "NBODY_BH_CLIMB_MAX": "0", "NBODY_BH_QUAD_MAX": "0"}
 
 
-def run(b, theta, env, steps):
+def run(b, theta, env, steps, **kw):
     for k in ALT: os.environ.pop(k, None)
     os.environ.update(env)
-    with nb.NBodySim(b.n, theta=theta, useBarnesHut=True) as sim:
+    with nb.NBodySim(b.n, theta=theta, useBarnesHut=True, **kw) as sim:
         sim.upload(*b.arrays())
         if steps: sim.step(steps)
         sim.compute_accel().sync()
@@ -54,6 +54,29 @@ def soak(seed, rounds):
             if not same_tree: status = f"TREE differs with {name}"; break
             if c != ref[3] or not np.array_equal(g[0], ref[4][0]) or not np.array_equal(g[1], ref[4][1]): status = f"COUNTERS differ with {name}"; break
             if not (np.array_equal(ax, ref[0]) and np.array_equal(ay, ref[1])): status = f"ACCELERATIONS differ with {name}"; break
+        if status == "ok" and steps == 0:
+            # shards: the targets of every rank of a random world size, walked on their own (i_begin != 0, ragged last
+            # shard), put together = the unsharded accelerations; with the default walk and with the alternative one
+            world = int(rng.integers(2, 9))
+            for env in ({}, {"NBODY_BH_QUAD_MAX": "0"}, {"NBODY_BH_QUAD_MAX": "100000000"}):
+                sx, sy = np.zeros_like(ref[0]), np.zeros_like(ref[1])
+                for rk in range(world):
+                    span = nb.shard_range(b.n, world, rk)
+                    ax, ay, t, c, g = run(b, theta, env, 0, shard=span)
+                    sx[span[0]:span[0] + span[1]] = ax[span[0]:span[0] + span[1]]
+                    sy[span[0]:span[0] + span[1]] = ay[span[0]:span[0] + span[1]]
+                if not (np.array_equal(sx, ref[0]) and np.array_equal(sy, ref[1])):
+                    status = f"SHARDS of {world} differ with {env}"
+                    ax, ay = sx, sy
+                    break
+        if status == "ok" and steps == 0 and kind != "close":
+            # bh_sorted (groups in tree order, ref_compat 0): its own result, every alternative against it
+            sref = run(b, theta, {}, 0, bh_sorted=True, ref_compat=0)
+            for name, env in [(f"{k}={v}", {k: v}) for k, v in ALT.items()] + [("sorted again", {})]:
+                ax, ay, t, c, g = run(b, theta, env, 0, bh_sorted=True, ref_compat=0)
+                if c != sref[3] or not (np.array_equal(ax, sref[0]) and np.array_equal(ay, sref[1])):
+                    status = f"BH_SORTED differs with {name}"
+                    break
         if status != "ok":                       # details, the input for a closer look, and is the DEFAULT path reproducible?
             out = os.path.join(ROOT, "gpurun_out", f"soak_fail_seed{seed}_round{r}.npz")
             os.makedirs(os.path.dirname(out), exist_ok=True)
