@@ -13,7 +13,8 @@ nb = e.load_package(); O = e.load_oracle()
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from bh_stress import make
 
-ALT = {"NBODY_BH_NO_FUSE": "1", "NBODY_BH_RANKSORT_MAX": "0", "NBODY_BH_CLIMB_MAX": "0", "NBODY_BH_QUAD_MAX": "0"}
+ALT = {"NBODY_BH_NO_FUSE": "1", "NBODY_BH_RANKSORT_MAX": "0", "NBODY_BH_CLIMB_MAX": "0", "NBODY_BH_QUAD_MAX": "0",
+       "NBODY_NO_GRAPH": "1"}                 # the last: eager launches instead of the captured step graph
 
 
 def run(b, theta, env, steps, **kw):
