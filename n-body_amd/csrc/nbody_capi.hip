@@ -57,7 +57,8 @@ struct Profiler {
 constexpr int kMaxSlices = 64;
 constexpr int kBhClimbMax = 1 << 21;         // bodies: up to here the centre-of-mass pass is ONE launch (bh_com_climb_kernel)
 constexpr float kBhSortedThetaScale = 0.6f;     // tools/bh_sorted_scale.py, profiles/r2_bh_sorted_scale.txt
-constexpr int kBhQuadMaxGroups = 6144;      // <= 49 152 targets: four waves per group (bh_walk_quad_kernel; measured crossover)
+constexpr int kBhQuadMaxGroups = 6144;      // four waves per group (bh_walk_quad_kernel) up to 49 152 targets at theta >= 1 ...
+constexpr int kBhQuadMinGroups = 3072;      // ... 24 576 at theta <= 0.5, linear in between (measured crossovers)
 constexpr size_t kMaxEventsPerClass = 4096;
 
 }  // namespace
@@ -348,11 +349,14 @@ int enqueue_bh_walk(nbody_ctx* ctx, int advance)
     EventPair* ep;
     int rc = profile_begin(ctx, 0, &ep);
     if (rc) return rc;
-    // Up to ~50 000 targets a group gets a workgroup of four waves (bh_walk_quad_kernel), above that 8 groups share a
-    // wave (bh_walk_kernel).  Measured walk us, quad / 8-per-wave (tools/bh_steady.py): N = 10 000 67 / 235,
-    // 32 768 186 / 330, 49 152 292 / 363, 65 536 369 / 374, 131 072 698 / 436.
+    // Few groups: a workgroup of four waves per group (bh_walk_quad_kernel); many: 8 groups share a wave (bh_walk_kernel).
+    // Where the second overtakes depends on the work per group, i.e. on theta.  Measured walk us, four-wave /
+    // 8-per-wave (tools/bh_steady.py): theta = 1: N = 10 000 67 / 235, 32 768 186 / 330, 49 152 292 / 363, 65 536 369 / 374,
+    // 131 072 698 / 436; theta = 0.7: 32 768 429 / 531, 49 152 698 / 608; theta = 0.5: 10 000 285 / 637, 20 000 632 / 832,
+    // 24 576 834 / 867, 32 768 1120 / 911; theta = 0.3: 20 000 1302 / 1814, 24 576 1749 / 1897, 32 768 2444 / 1996.
     const int groups = (nt + 7) / 8;
-    int quad_max = kBhQuadMaxGroups;
+    const float tq = w.theta < 0.5f ? 0.5f : (w.theta > 1.0f ? 1.0f : w.theta);
+    int quad_max = kBhQuadMinGroups + (int)((tq - 0.5f) * 2.0f * (float)(kBhQuadMaxGroups - kBhQuadMinGroups));
     if (const char* e = std::getenv("NBODY_BH_QUAD_MAX")) quad_max = std::atoi(e);              // developer/test switch
     if (groups <= quad_max) {
         w.lanes_used = 8;
