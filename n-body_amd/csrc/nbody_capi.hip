@@ -355,7 +355,10 @@ int enqueue_bh_walk(nbody_ctx* ctx, int advance)
     // 131 072 698 / 436; theta = 0.7: 32 768 429 / 531, 49 152 698 / 608; theta = 0.5: 10 000 285 / 637, 20 000 632 / 832,
     // 24 576 834 / 867, 32 768 1120 / 911; theta = 0.3: 20 000 1302 / 1814, 24 576 1749 / 1897, 32 768 2444 / 1996.
     const int groups = (nt + 7) / 8;
-    const float tq = w.theta < 0.5f ? 0.5f : (w.theta > 1.0f ? 1.0f : w.theta);
+    // (the nominal theta also for bh_sorted: its 0.6 theta vote on compact groups costs about as many visits per group
+    // as the nominal theta on scattered ones, and the measured crossovers are the same)
+    const float tn = ctx->cfg.theta;
+    const float tq = tn < 0.5f ? 0.5f : (tn > 1.0f ? 1.0f : tn);
     int quad_max = kBhQuadMinGroups + (int)((tq - 0.5f) * 2.0f * (float)(kBhQuadMaxGroups - kBhQuadMinGroups));
     if (const char* e = std::getenv("NBODY_BH_QUAD_MAX")) quad_max = std::atoi(e);              // developer/test switch
     if (groups <= quad_max) {

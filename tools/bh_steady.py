@@ -1,6 +1,6 @@
 """Developer tool: steady-state time of one Barnes-Hut force evaluation (build + walk, state unchanged) after the
 chip's clocks have ramped up: REPS evaluations back to back, per-kernel-class event times over the last quarter.
-    python tools/bh_steady.py [N [theta [reps]]]"""
+    python tools/bh_steady.py [N [theta [reps [sorted]]]]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as e
@@ -9,7 +9,8 @@ from nbody_amd import initial_conditions as ic
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 theta = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
-sim = nb.NBodySim(n, theta=theta, useBarnesHut=True); sim.upload(*ic.disc(n, seed=12345))
+srt = dict(bh_sorted=True, ref_compat=0) if len(sys.argv) > 4 and sys.argv[4] == "sorted" else {}
+sim = nb.NBodySim(n, theta=theta, useBarnesHut=True, **srt); sim.upload(*ic.disc(n, seed=12345))
 for phase in ("cold", "warm"):
     sim.profile(True).profile_reset()
     k = 5 if phase == "cold" else reps
