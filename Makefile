@@ -21,7 +21,12 @@ lib-timing: $(CSRC)/nbody_capi.hip $(KERNEL_HDRS)
 	$(HIPCC) $(HIPFLAGS) -DNBODY_WIDE_TIMING -shared $< -o $(PKG)/lib/libnbody_amd_timing.so -ldl
 
 # C++ host drivers: counterparts of the reference's benchmark.cpp / main.cpp loops, calling the C-ABI.
-host: $(PKG)/bin/nbody_benchmark $(PKG)/bin/nbody_sim
+host: $(PKG)/bin/nbody_benchmark $(PKG)/bin/nbody_sim $(PKG)/bin/exact_core_check
+
+# GPU self-check of csrc/exact_core.hip.h against hipcc's IEEE sqrt / division (tests/test_gpu_exact_core.py)
+$(PKG)/bin/exact_core_check: tools/exact_core_check.hip $(CSRC)/exact_core.hip.h
+	@mkdir -p $(PKG)/bin
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Wno-format $< -o $@
 
 $(PKG)/bin/nbody_benchmark: $(PKG)/host/benchmark_main.cpp $(PKG)/host/config_reader.hpp $(PKG)/host/initial_conditions.hpp include/nbody.h $(LIB)
 	@mkdir -p $(PKG)/bin

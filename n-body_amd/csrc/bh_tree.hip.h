@@ -47,6 +47,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "exact_core.hip.h"
 
 namespace nbody {
 
@@ -996,6 +997,7 @@ struct BhWalkArgs {
     int* __restrict__ grp_visits;    // [n/8 + 1] per group of 8 bodies (index = first body / 8): nodes popped and
     int* __restrict__ grp_accepts;   //           nodes accepted by this walk (parity hook, nbody_bh_group_counters)
     const int* __restrict__ order;   // bh_sorted: walk position -> body (the build's sorted order); nullptr: identity
+    int exact_core;                  // 1: masses and radii are in the range exact_core.hip.h needs (checked at upload)
 };
 
 // Groups per wave.  8 (all 64 lanes) is the throughput shape.  With few groups the walk is a latency chain and the
@@ -1077,14 +1079,22 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
                     ++accepts;
                     // computeForce_kernel, benchmark.cpp:188-225: the accepted term is computed in IEEE arithmetic
                     // (correctly rounded sqrt and divisions) unless bh_fast_math asked for the hardware's
-                    if constexpr (!kFast) d = __builtin_sqrtf(d2);                  // :193-194
-                    const float sd = __builtin_fmaxf(d, ri);    // clamp radius is the TARGET's only (:201-202)
+                    // (IEEE: the same correctly rounded results from exact_core.hip.h's shorter sequences when every
+                    // accepting lane's d^2 is in their range — all but the self and far-escaped cases —, else hipcc's)
                     float f;
                     if constexpr (kFast) {
+                        const float sd = __builtin_fmaxf(d, ri);    // clamp radius is the TARGET's only (:201-202)
                         f = a.z * __builtin_amdgcn_rcpf(__builtin_fmaf(sd, sd, soft2));
+                    } else if (w.exact_core && __ballot(!(d2 >= kCoreD2Min && d2 <= kCoreD2Max)) == 0ull) {
+                        d = core_sqrt_rn(d2, d);                                    // :193-194
+                        const float sd = __builtin_fmaxf(d, ri);
+                        f = core_div_rn(a.z, __builtin_fmaf(sd, sd, soft2));        // :203-209
+                        inv = core_rcp_rn(d + eps);                                 // :212-213
                     } else {
-                        f = a.z / __builtin_fmaf(sd, sd, soft2);   // :203-209
-                        inv = 1.0f / (d + eps);                    // :212-213
+                        d = __builtin_sqrtf(d2);
+                        const float sd = __builtin_fmaxf(d, ri);
+                        f = a.z / __builtin_fmaf(sd, sd, soft2);
+                        inv = 1.0f / (d + eps);
                     }
                     const bool self = b.y == i;                 // :197-198
                     ax = ax + (self ? 0.0f : (dx * inv) * f);
@@ -1360,11 +1370,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBODY_QUAD_
             inv = __builtin_amdgcn_rcpf(d + eps);
             const float sd = __builtin_fmaxf(d, ri);
             f = a.z * __builtin_amdgcn_rcpf(__builtin_fmaf(sd, sd, soft2));
+        } else if (w.exact_core && __ballot(!(d2 >= kCoreD2Min && d2 <= kCoreD2Max)) == 0ull) {
+            // correctly rounded, by exact_core.hip.h's shorter sequences: every lane's d^2 is in their range
+            d = core_sqrt_rn(d2, __builtin_amdgcn_sqrtf(d2));
+            const float sd = __builtin_fmaxf(d, ri);                   // :201-202
+            f = core_div_rn(a.z, __builtin_fmaf(sd, sd, soft2));       // :203-209
+            inv = core_rcp_rn(d + eps);                                // :212-213
         } else {
             d = __builtin_sqrtf(d2);
-            const float sd = __builtin_fmaxf(d, ri);                   // :201-202
-            f = a.z / __builtin_fmaf(sd, sd, soft2);                   // :203-209
-            inv = 1.0f / (d + eps);                                    // :212-213
+            const float sd = __builtin_fmaxf(d, ri);
+            f = a.z / __builtin_fmaf(sd, sd, soft2);
+            inv = 1.0f / (d + eps);
         }
         const bool self = b.y == i;                                    // :197-198
         tx = self ? 0.0f : (dx * inv) * f;

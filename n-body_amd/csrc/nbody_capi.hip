@@ -77,6 +77,7 @@ struct nbody_ctx {
     int diag_blocks = 0;
     int i_begin = 0, i_end = 0;      // targets actually advanced (shard ∩ ref_compat limit)
     int i_stride = 0;
+    bool bh_exact_core = false;      // masses / radii within exact_core.hip.h's ranges (nbody_upload)
     int variant = 0, slices = 1, k_per_lane = 2, j_per_slice = 0, blocks_x = 0, tile = 0, partial_rows = 0;
     float uni_c = 0, pre_scale = 1, out_scale = 1;
     bool uploaded = false;
@@ -336,6 +337,7 @@ int enqueue_bh_walk(nbody_ctx* ctx, int advance)
         }
     }
     w.dt = ctx->cfg.dt; w.advance = advance;
+    w.exact_core = ctx->bh_exact_core ? 1 : 0;
     w.i_begin = ctx->i_begin; w.i_end = ctx->i_end;
     // bh_sorted: compact groups accept a node as soon as ONE patch is far from it, where the reference's scattered
     // groups need eight unrelated places to be; at the same threshold that is a larger error (measured 2x).  The
@@ -644,9 +646,11 @@ int nbody_upload(nbody_ctx* ctx, const float* m, const float* posX, const float*
     HIP_TRY(hipSetDevice(ctx->device));
     const int n = ctx->cfg.num_bodies;
     // Choose the pair-formula variant from the data (see force_naive.hip.h for the conditions).
-    bool uni_m = true, uni_r = true, finite = true;
+    bool uni_m = true, uni_r = true, finite = true, core_ok = true;
     float rmin = radius[0];
     for (int i = 0; i < n; ++i) {
+        // Barnes-Hut node kernel: operand ranges of the short correctly rounded sequences (exact_core.hip.h)
+        core_ok &= (m[i] == 0.0f || (m[i] >= kCoreMassMin && m[i] <= kCoreMassMax)) && radius[i] >= 0.0f && radius[i] <= kCoreMassMax;
         uni_m &= (m[i] == m[0]);
         uni_r &= (radius[i] == radius[0]);
         rmin = radius[i] < rmin ? radius[i] : rmin;
@@ -668,6 +672,7 @@ int nbody_upload(nbody_ctx* ctx, const float* m, const float* posX, const float*
     if (variant != kExact && !clamp_ok)
         return fail(NBODY_ERR_INVALID, "nbody_upload: force_variant %d needs every radius >= 4 (min %g)", variant, rmin);
     ctx->variant = variant;
+    ctx->bh_exact_core = core_ok && !std::getenv("NBODY_BH_NO_CORE");
     ctx->uni_c = 1.0f / (r0 * r0 + kSoft2);
     ctx->pre_scale = variant == kScaled ? 1.0f / r0 : 1.0f;
     ctx->out_scale = variant == kScaled ? m[0] / (r0 * r0) : (variant == kUniform ? m[0] : 1.0f);

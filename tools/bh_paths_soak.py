@@ -14,7 +14,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from bh_stress import make
 
 ALT = {"NBODY_BH_NO_FUSE": "1", "NBODY_BH_RANKSORT_MAX": "0", "NBODY_BH_CLIMB_MAX": "0", "NBODY_BH_QUAD_MAX": "0",
-       "NBODY_NO_GRAPH": "1"}                 # the last: eager launches instead of the captured step graph
+       "NBODY_NO_GRAPH": "1",                 # eager launches instead of the captured step graph
+       "NBODY_BH_NO_CORE": "1"}               # hipcc's IEEE sqrt and divisions instead of exact_core.hip.h's sequences
 
 
 def run(b, theta, env, steps, **kw):
