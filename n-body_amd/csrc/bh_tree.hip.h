@@ -1056,7 +1056,8 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
             // node's arithmetic.  Same-box A/B: no gain at N = 10^4..65 536, 28 % slower at N = 10^6; not kept.
             // Tried: the whole body as straight-line predicated code (selects instead of nested branches): 110 ->
             // 75 instructions per iteration, but the divisions then run for every group in every iteration:
-            // +8 % at N = 10^6 (IEEE) / +4 % (fast math), -14 % at N = 10^4; not kept.)
+            // +8 % at N = 10^6 (IEEE) / +4 % (fast math), -14 % at N = 10^4; not kept.  Tried again once the node
+            // kernel had shrunk to exact_core.hip.h's 26 instructions: 2.17 against 2.03 ms at N = 10^6; not kept.)
             const bool more_siblings = node != 0 && ((node - 1) & 3) != 0;
             ++visits;
             bool open = false;
