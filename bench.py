@@ -282,7 +282,7 @@ def main():
                          "build_ms": build_ms / max(1, build_launches), "launches": int(force_launches),
                          "node_visits_step1": int(cnt["visits"]), "accepted_nodes_step1": int(cnt["accepts"]),
                          "note": "tree walk priced in bytes (24 B per group-visit of rank 0's launch, SURVEY.md §8d: no flop "
-                                 "convention); counters show it VALU-issue-bound at N=1e6 (98 VALU instructions per wave "
+                                 "convention); counters show it VALU-issue-bound at N=1e6 (78 VALU instructions per wave "
                                  "iteration, 85 % L2 hits, profiles/README.md), so the HBM fraction is a floor, not a target"},
         }
         if world == 1 and n == 1_000_000 and args.theta == 1.0 and not args.bh_fast_math:
