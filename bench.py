@@ -263,6 +263,10 @@ def main():
     if rank == 0 and bh:
         build_ms, build_launches = sim.sim.profile_read(2)
         cnt = sim.sim.bh_counters()
+        # which walk kernel the library's host code picks (nbody_capi.hip, enqueue_bh_walk): four waves per group up to
+        # 3072 ... 6144 groups of 8 targets depending on theta, 8 groups per wave above
+        groups = (sim.spans[rank][1] + 7) // 8
+        walk_kernel = "bh_walk_quad_kernel" if groups <= 3072 + int((min(max(args.theta, 0.5), 1.0) - 0.5) * 2 * 3072) else "bh_walk_kernel"
         walk_ms = force_ms / max(1, force_launches)
         # algorithmic bytes of one walk launch: one 24-B node record (float4 + int2) per group-visit
         walk_gbs = 24.0 * cnt["visits"] / (walk_ms * 1e-3) / 1e9
@@ -278,7 +282,7 @@ def main():
                        "grouping": "bh_sorted: 8 consecutive bodies of the tree's quadrant-path order, vote at 0.7 theta" if args.bh_sorted
                                    else "reference: 8 consecutive body indices (benchmark.cpp:366-380)"},
             "roofline": {"bound": "hbm", "achieved": walk_gbs, "peak": 8000.0, "unit": "GB/s", "frac": walk_gbs / 8000.0,
-                         "traffic": None, "kernel": "bh_walk_kernel", "kernel_ms": walk_ms, "clock": clock,
+                         "traffic": None, "kernel": walk_kernel, "kernel_ms": walk_ms, "clock": clock,
                          "build_ms": build_ms / max(1, build_launches), "launches": int(force_launches),
                          "node_visits_step1": int(cnt["visits"]), "accepted_nodes_step1": int(cnt["accepts"]),
                          "note": "tree walk priced in bytes (24 B per group-visit of rank 0's launch, SURVEY.md §8d: no flop "
