@@ -110,7 +110,8 @@ __global__ __launch_bounds__(kBhBlock) void bh_keys_kernel(const float* __restri
                                                            int fixed_box, uint64_t* __restrict__ keys,
                                                            int* __restrict__ vals, uint16_t* __restrict__ tie,
                                                            uint64_t* __restrict__ gkeys, int* __restrict__ gvals, int gcap,
-                                                           int* __restrict__ tie_table, int tie_table_size, int count_valid)
+                                                           int* __restrict__ tie_table, int tie_table_size, int count_valid,
+                                                           const float* __restrict__ m, float4* __restrict__ body4)
 {
     const int i = blockIdx.x * kBhBlock + threadIdx.x;
     for (int g = i; g < gcap; g += gridDim.x * kBhBlock) { gkeys[g] = ~0ull; gvals[g] = -1; }
@@ -142,6 +143,10 @@ __global__ __launch_bounds__(kBhBlock) void bh_keys_kernel(const float* __restri
         keys[i] = key;
         vals[i] = i;
         tie[i] = (uint16_t)(tx | (ty << 8));
+        // {x, y, m} of the body in ONE record: bh_nodes_kernel gathers the leaves' bodies by index, and a random 4-byte
+        // read costs a whole memory sector — one sector per body instead of three (0.67 of the 2.0 ms the node kernel
+        // took at N = 2^24 was this gather)
+        body4[i] = make_float4(x, y, m[i], 0.0f);
     }
     // small-N build (count_valid): number of in-box bodies = where the invalid keys start after the sort, one atomic
     // per wave.  Measured: same-line device-scope atomics cost ~4 ns each and a short kernel cannot end before they
@@ -744,7 +749,8 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
                                                             const float* __restrict__ py, BhTree t,
                                                             BhCounters* __restrict__ ctr, int* __restrict__ overflow_host,
                                                             const uint64_t* __restrict__ keys_unmerged,
-                                                            const int* __restrict__ vals_unmerged)
+                                                            const int* __restrict__ vals_unmerged,
+                                                            const float4* __restrict__ body4)
 {
     // small-N build: without second instances the merged arrays were never written, they ARE the sorted primaries
     if (keys_unmerged != nullptr && ctr->ghosts == 0) { keys = keys_unmerged; vals = vals_unmerged; }
@@ -761,7 +767,8 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
         for (int k = 0; k < 64; ++k) ctr->valid_part[k] = 0;            // everybody has read ctr->valid by now
         if (M < 2) {                                           // degenerate trees: root is a leaf / empty
             const int b = M == 1 ? vals[0] : -1;
-            t.A[0] = make_float4(b >= 0 ? px[b] : 0.0f, b >= 0 ? py[b] : 0.0f, b >= 0 ? m[b] : 0.0f, 2.0f * spread);
+            const float4 p = b >= 0 ? body4[b] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            t.A[0] = make_float4(p.x, p.y, p.z, 2.0f * spread);
             t.B[0] = make_int2(-1, b);
         }
     }
@@ -822,7 +829,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
         } else if (cntq >= 1) {
             body = vals[s[q]];                                  // leaf
         }
-        if (body >= 0) { cx = px[body]; cy = py[body]; cm = m[body]; }   // benchmark.cpp:89-92
+        if (body >= 0) { const float4 p = body4[body]; cx = p.x; cy = p.y; cm = p.z; }   // benchmark.cpp:89-92
         if (child_base < 0 && cntq >= 2) {
             // Several bodies in one cell that is not split further: closer together than the finest cell (the path
             // key has 31 levels: 800/2^31 = 3.7e-7 at spread 400) or the pool is exhausted.  The reference keeps
@@ -834,10 +841,11 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
             for (int j = s[q]; j < s[q + 1]; ++j) {
                 const int bj = vals[j];
                 if (j > s[q] && bj == vals[j - 1]) continue;    // two instances of one body
-                const float mj = m[bj];
+                const float4 p = body4[bj];
+                const float mj = p.z;
                 ms += mj;
-                sx = __builtin_fmaf(px[bj], mj, sx);
-                sy = __builtin_fmaf(py[bj], mj, sy);
+                sx = __builtin_fmaf(p.x, mj, sx);
+                sy = __builtin_fmaf(p.y, mj, sy);
             }
             cm = ms;
             if (ms > 0.0f) { cx = sx / ms; cy = sy / ms; }

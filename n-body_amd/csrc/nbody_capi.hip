@@ -126,6 +126,7 @@ struct nbody_ctx {
         void* own_sort_tmp = nullptr;
         size_t own_sort_bytes = 0;
         int *rank = nullptr, *rank_done = nullptr;   // small-N rank sort: partial ranks [n], per-tile arrival counters,
+        float4* body4 = nullptr;                     // {x, y, m, 0} per body, written by bh_keys_kernel for the node kernel's gathers
         unsigned char* tie_first_sorted = nullptr;   //   first split-line level of each body, in sorted order [n]
         void *sort_tmp = nullptr, *scan_tmp = nullptr;
         size_t sort_bytes = 0, scan_bytes = 0;
@@ -260,7 +261,7 @@ int enqueue_bh_build(nbody_ctx* ctx)
     }
     const bool fused = n <= kBhSmallMax && b.gcap <= kBhSmallGhosts && !std::getenv("NBODY_BH_NO_FUSE");
     bh_keys_kernel<<<grid_n, blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr, ctx->cfg.spread, adaptive ? 0 : 1, b.keys, b.vals, b.tie,
-                                          b.gkeys, b.gvals, b.gcap, b.tie_table, b.tie_table_size, fused ? 1 : 0);
+                                          b.gkeys, b.gvals, b.gcap, b.tie_table, b.tie_table_size, fused ? 1 : 0, ctx->m, b.body4);
     const char* rank_env = std::getenv("NBODY_BH_RANKSORT_MAX");         // developer/test switch
     const bool ranked = fused && n <= (rank_env ? std::atoi(rank_env) : kBhRankSortMax);
     if (ranked) {
@@ -297,7 +298,7 @@ int enqueue_bh_build(nbody_ctx* ctx)
     const dim3 grid_c((b.tree.cap_internal + kBhBlock - 1) / kBhBlock);
     bh_nodes_kernel<<<grid_c, blk, 0, s>>>(b.keys_merged, b.vals_merged, b.cnt, b.base, b.owner, nm, ctx->m, ctx->px, ctx->py,
                                            b.tree, b.ctr, b.overflow_dev, fused ? b.keys_sorted : nullptr,
-                                           fused ? b.vals_sorted : nullptr);
+                                           fused ? b.vals_sorted : nullptr, b.body4);
     // centre of mass: one launch in which the last child to finish evaluates its parent; for very large trees one
     // launch per depth (31 launches of >= 4.5 us, but their loads hit the L2: faster above ~2 x 10^6 bodies)
     const char* climb_env = std::getenv("NBODY_BH_CLIMB_MAX");          // developer/test switch, read per enqueue
@@ -558,6 +559,7 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
         HIP_TRY_C(hipMalloc((void**)&b.tree.depth, (size_t)b.tree.cap_internal + 16));   // read 16 bytes at a time
         HIP_TRY_C(hipMalloc((void**)&b.tree.self, sizeof(int) * (size_t)b.tree.cap_internal));
         HIP_TRY_C(hipMalloc((void**)&b.tree.pend, sizeof(int) * (size_t)b.tree.cap_internal));
+        HIP_TRY_C(hipMalloc((void**)&b.body4, sizeof(float4) * (size_t)n));
         if (n <= kBhRankSortMax) {                             // both stay zero between builds (the kernel re-zeroes them)
             HIP_TRY_C(hipMalloc((void**)&b.rank, sizeof(int) * (size_t)n));
             HIP_TRY_C(hipMalloc((void**)&b.rank_done, sizeof(int) * ((size_t)n / kBhBlock + 1)));
@@ -606,7 +608,7 @@ void nbody_destroy(nbody_ctx* ctx)
     {
         auto& b = ctx->bh;
         void* ptrs[] = {b.keys, b.keys_sorted, b.vals, b.vals_sorted, b.cnt, b.base, b.tree.A, b.tree.B,
-                        b.tree.depth, b.tree.self, b.tree.pend, b.rank, b.rank_done, b.tie_first_sorted, b.ctr, b.tie, b.owner, b.gfx, b.gfy, b.gld, b.pld, b.glo, b.ghi, b.gpos, b.tie_table, b.sort_tmp, b.scan_tmp, b.gkeys, b.gkeys_sorted, b.gvals,
+                        b.tree.depth, b.tree.self, b.tree.pend, b.rank, b.rank_done, b.tie_first_sorted, b.body4, b.ctr, b.tie, b.owner, b.gfx, b.gfy, b.gld, b.pld, b.glo, b.ghi, b.gpos, b.tie_table, b.sort_tmp, b.scan_tmp, b.gkeys, b.gkeys_sorted, b.gvals,
                         b.gvals_sorted, b.keys_merged, b.vals_merged, b.gsort_tmp, b.grp_visits, b.grp_accepts,
                         b.own_keys_sorted, b.own_order, b.own_sort_tmp};
         for (void* p : ptrs)
