@@ -936,6 +936,8 @@ __global__ __launch_bounds__(kBhBlock) void bh_com_kernel(BhTree t, const BhCoun
 // written or read with ORDINARY stores and loads — there is none here.  With them (a plain __threadfence() on either
 // side of the atomic) the N = 10^6 build takes 3.2 ms instead of 0.52: every fence writes back / invalidates the whole
 // L2 for everybody.
+// kAgentLoads = false: the cell's children are all leaves, written by the PREVIOUS kernel — ordinary (cached) loads do.
+template <bool kAgentLoads>
 __device__ __forceinline__ void bh_com_cell_agent(const BhTree& t, int c)
 {
     const int self = t.self[c];
@@ -944,8 +946,14 @@ __device__ __forceinline__ void bh_com_cell_agent(const BhTree& t, int c)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const unsigned long long* p = reinterpret_cast<const unsigned long long*>(t.A + 1 + 4 * c + q);
-        xy[q] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        mz[q] = __hip_atomic_load(reinterpret_cast<const unsigned*>(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (kAgentLoads) {
+            xy[q] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mz[q] = __hip_atomic_load(reinterpret_cast<const unsigned*>(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const float4 a = t.A[1 + 4 * c + q];
+            xy[q] = (unsigned long long)__float_as_uint(a.x) | ((unsigned long long)__float_as_uint(a.y) << 32);
+            mz[q] = __float_as_uint(a.z);
+        }
     }
     float ms = 0.0f, sx = 0.0f, sy = 0.0f;
 #pragma unroll
@@ -973,7 +981,8 @@ __global__ __launch_bounds__(kBhBlock) void bh_com_climb_kernel(BhTree t, const 
     if (c >= I) return;
     if (t.pend[c] != -1) return;                   // has internal children: the last of them to finish takes it
     for (int hop = 0; hop <= kBhLevels; ++hop) {
-        bh_com_cell_agent(t, c);
+        if (hop == 0) bh_com_cell_agent<false>(t, c);          // a cell without internal children: only leaves below
+        else          bh_com_cell_agent<true>(t, c);
         if (c == 0) break;
         const int p = (t.self[c] - 1) >> 2;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // compiler: nothing moves below
