@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
                         d = core_sqrt_rn(d2, d);                                    // :193-194
                         const float sd = __builtin_fmaxf(d, ri);
                         f = core_div_rn(a.z, __builtin_fmaf(sd, sd, soft2));        // :203-209
-                        inv = core_rcp_rn(d + eps);                                 // :212-213
+                        inv = core_rcp_rn_seeded(d + eps, inv);                     // :212-213, from the vote's v_rcp
                     } else {
                         d = __builtin_sqrtf(d2);
                         const float sd = __builtin_fmaxf(d, ri);

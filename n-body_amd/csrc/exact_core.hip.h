@@ -68,4 +68,21 @@ __device__ __forceinline__ float core_rcp_rn(float b)
     return __builtin_fmaf(t, r, q);
 }
 
+// 1 / (d + eps) correctly rounded for d = core_sqrt_rn(x, s), starting the Newton step from r0 = v_rcp_f32(s + eps) — the
+// reciprocal the walk's vote has already taken of the 1-ulp distance s = v_sqrt_f32(x) — instead of a new
+// v_rcp_f32(d + eps).  r0 is within 3 ulp of 1 / (d + eps); the Newton step squares that error away and the two
+// residual corrections do the rounding.  Not the compiler's sequence any more, so not identical by construction:
+// tools/exact_core_check.hip checks it against 1.0f / (d + eps) for EVERY x of the sqrt range.
+__device__ __forceinline__ float core_rcp_rn_seeded(float b, float r0)
+{
+#pragma clang fp contract(off)
+    const float e = __builtin_fmaf(-b, r0, 1.0f);
+    const float r = __builtin_fmaf(e, r0, r0);
+    float q = r;
+    float t = __builtin_fmaf(-b, q, 1.0f);
+    q = __builtin_fmaf(t, r, q);
+    t = __builtin_fmaf(-b, q, 1.0f);
+    return __builtin_fmaf(t, r, q);
+}
+
 }  // namespace nbody
