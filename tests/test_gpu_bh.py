@@ -380,6 +380,24 @@ def test_alternative_kernels_agree_on_adversarial_inputs(nb, O):
     assert mod.soak(1, 60) == 0
 
 
+@pytest.mark.parametrize("mass,radius", [(1e-15, 8.0), (1e15, 8.0), (1000.0, 3e12), (1000.0, 0.0)])
+def test_masses_and_radii_outside_the_short_sequences_range(nb, O, mass, radius):
+    """exact_core.hip.h's short correctly rounded sequences need masses in {0} u [2^-40, 2^40] and radii in [0, 2^40];
+    nbody_upload checks that and the walk falls back to hipcc's own IEEE expansions otherwise (first three cases; the
+    fourth, radius 0, is inside the range but makes the softened denominator as small as it gets).  Bit-equal to the
+    oracle either way, with both walk kernels (N = 3000: four waves per group; N = 60 000: 8 groups per wave)."""
+    for n in (3000, 60000):
+        b = O.init_disc(n, seed=31)
+        b.m[:] = np.float32(mass)
+        b.m[::7] = 0.0                                                   # massless bodies in any case
+        b.radius[:] = np.float32(radius)
+        ax, ay, _, _, cnt = gpu_bh(nb, b)
+        ot = O.Tree(n).build(b, 400.0)
+        ox, oy, ocnt = ot.accel(b, 1.0)
+        assert cnt == ocnt
+        assert np.array_equal(ax, ox.astype(np.float32)) and np.array_equal(ay, oy.astype(np.float32))
+
+
 def ot_depth_of(pool):
     depth, stack = 0, [(0, 0)]
     while stack:
