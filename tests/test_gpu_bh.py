@@ -398,6 +398,24 @@ def test_masses_and_radii_outside_the_short_sequences_range(nb, O, mass, radius)
         assert np.array_equal(ax, ox.astype(np.float32)) and np.array_equal(ay, oy.astype(np.float32))
 
 
+def test_targets_far_outside_the_short_sequences_distance_range(nb, O):
+    """The short sequences accept 2^-96 <= d^2 <= 2^80; a wave with an accepting lane outside takes hipcc's expansions
+    for that node.  Bodies that have escaped to 1e15 (d^2 = 1e30) and 1e25 (d^2 overflows to inf: the reference's
+    arithmetic then gives +-0 terms) are targets like any other (benchmark.cpp:366-380 walks every body), and bodies
+    exactly at a node's centre of mass have d^2 = 0: all bit-equal to the oracle, both walk kernels."""
+    for n in (3000, 60000):
+        b = O.init_disc(n, seed=32)
+        b.posX[5], b.posY[5] = np.float32(1e15), np.float32(-3e14)
+        b.posX[n // 2], b.posY[n // 2] = np.float32(-1e25), np.float32(1e25)
+        b.posX[n - 3], b.posY[n - 3] = np.float32(3e7), np.float32(2.0)
+        ax, ay, _, _, cnt = gpu_bh(nb, b)
+        ot = O.Tree(n).build(b, 400.0)
+        ox, oy, ocnt = ot.accel(b, 1.0)
+        assert cnt == ocnt
+        assert np.array_equal(ax.view(np.uint32), ox.astype(np.float32).view(np.uint32))
+        assert np.array_equal(ay.view(np.uint32), oy.astype(np.float32).view(np.uint32))
+
+
 def ot_depth_of(pool):
     depth, stack = 0, [(0, 0)]
     while stack:
