@@ -169,6 +169,42 @@ def cpu_baseline_bh(n, theta):
                        f"median of steps 1-3")
 
 
+def self_launch(gpus):
+    """`python bench.py --gpus N` from a plain interpreter: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child in its own
+    process group, relay its stdout (rank 0's one JSON line) and stderr, return its exit code; on a time limit
+    (NBODY_LAUNCH_TIMEOUT, default 900 s) kill exactly that process group.  The ranks arm their own watchdogs."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    limit = float(os.environ.get("NBODY_LAUNCH_TIMEOUT", "900"))
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)       # stdout/stderr inherited: the line goes straight out
+    try:
+        return proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the {gpus}-rank job did not finish within {limit:.0f} s; killing its process group", file=sys.stderr, flush=True)
+        try:
+            os.killpg(proc.pid, signal.SIGTERM)
+            proc.wait(timeout=15)
+        except (ProcessLookupError, subprocess.TimeoutExpired):
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+        return 124
+    except KeyboardInterrupt:
+        os.killpg(proc.pid, signal.SIGTERM)
+        raise
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,21 +218,32 @@ def main():
     ap.add_argument("--bh-fast-math", action="store_true",
                     help="bh workload: 1-ulp hardware sqrt/rcp in the walk (same votes, terms differ by a few ulp)")
     ap.add_argument("--bh-sorted", action="store_true",
-                    help="bh workload: groups of 8 in the tree's own space-filling order, vote at 0.7 theta (ref_compat 0; not the reference's grouping)")
+                    help="bh workload: groups of 8 in the tree's own space-filling order, vote at 0.6 theta (ref_compat 0; not the reference's grouping)")
     args = ap.parse_args()
-    if os.environ.get("NBODY_DEBUG") or os.environ.get("NBODY_DIST_BACKEND", "nccl") != "nccl":
-        # a stalled rank reports where it stands instead of hanging its launcher (always on in the gloo rehearsal)
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ.get("NBODY_DEBUG_TIMEOUT", "90")), exit=True)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # called as plain `python bench.py --gpus N`: start the N ranks ourselves.  Nothing in THIS process has touched
+        # the GPU (no torch import yet), and the ranks are fresh children, never an exec of an initialised process.
+        raise SystemExit(self_launch(args.gpus))
+    import faulthandler
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 or os.environ.get("NBODY_DEBUG"):
+        # A stalled rank (first contact with RCCL over xGMI, a rendezvous that never completes, the gloo rehearsal)
+        # dumps every thread's stack and exits instead of hanging its launcher: armed for EVERY backend when world > 1.
+        # Generous while `import torch` pages in on a fresh box (1-2 minutes); re-armed per phase below.
+        faulthandler.dump_traceback_later(int(os.environ.get("NBODY_IMPORT_TIMEOUT", "420")), exit=True)
+
+    def watchdog(phase_s=None):
+        if world > 1 or os.environ.get("NBODY_DEBUG"):
+            faulthandler.cancel_dump_traceback_later()
+            if phase_s is not None:
+                faulthandler.dump_traceback_later(int(os.environ.get("NBODY_DEBUG_TIMEOUT", str(phase_s))), exit=True)
 
     import torch
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    watchdog(120)                                  # process group + context + upload
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     # one rank per GPU; NBODY_DIST_BACKEND=gloo + fewer GPUs than ranks is the single-GPU rehearsal of the N>1 path
@@ -230,6 +277,8 @@ def main():
         torch.cuda.synchronize()
 
     sampler = ClockSampler(local_rank).start() if rank == 0 else None
+    # warm-up + timed steps: ~0.2 s per naive step at N = 2^20 on one GPU
+    watchdog(120 + int(2.0 * (args.steps + args.warmup) * max(1.0, (n / float(1 << 20)) ** 2) / world))
     barrier()
     t_load = time.perf_counter()
     sim.step(args.warmup)
@@ -279,7 +328,7 @@ def main():
                                    f"(warm-up ran on the same context, then the initial state was uploaded again)",
                        "num_bodies": n, "parallelism": f"tree replicated, walk i-sharded x{world}",
                        "arithmetic": "hardware sqrt/rcp, exact vote" if args.bh_fast_math else "IEEE (bit-identical to the oracle)",
-                       "grouping": "bh_sorted: 8 consecutive bodies of the tree's quadrant-path order, vote at 0.7 theta" if args.bh_sorted
+                       "grouping": "bh_sorted: 8 consecutive bodies of the tree's quadrant-path order, vote at 0.6 theta" if args.bh_sorted
                                    else "reference: 8 consecutive body indices (benchmark.cpp:366-380)"},
             "roofline": {"bound": "hbm", "achieved": walk_gbs, "peak": 8000.0, "unit": "GB/s", "frac": walk_gbs / 8000.0,
                          "traffic": None, "kernel": walk_kernel, "kernel_ms": walk_ms, "clock": clock,
@@ -344,9 +393,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
+    watchdog(60)
     sim.close()
     if world > 1:
         dist.destroy_process_group()
+    watchdog(None)
 
 
 if __name__ == "__main__":

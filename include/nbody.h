@@ -23,7 +23,9 @@
 extern "C" {
 #endif
 
-#define NBODY_ABI_VERSION 1
+/* 2: + nbody_upload_state, nbody_comm_plan, nbody_profile_samples, nbody_bh_group_counters, nbody_accel_noalloc,
+      nbody_config.bh_sorted (was reserved[0]); nbody_step(ctx, n > 1) on a partial shard is refused / exchanges (round 3) */
+#define NBODY_ABI_VERSION 2
 
 enum {
     NBODY_OK = 0,
@@ -113,8 +115,11 @@ int nbody_upload(nbody_ctx *ctx, const float *m, const float *posX, const float 
 int nbody_upload_state(nbody_ctx *ctx, const float *posX, const float *posY, const float *velX, const float *velY);
 
 /* Enqueue nsteps iterations of the block benchmark.cpp:354-511 (force + forward Euler).  Returns
-   once enqueued.  In a sharded context only the owned i-range is advanced; the caller all-gathers the
-   position arrays (nbody_device_ptr) between steps, so nsteps must be 1 there. */
+   once enqueued.  In a sharded context only the owned i-range is advanced and the position arrays have to be
+   all-gathered between steps: nsteps == 1 leaves that to the caller (nbody_device_ptr + its own collective, or
+   nbody_exchange_positions); nsteps > 1 runs nsteps x (step + nbody_exchange_positions) when a communicator is
+   attached (nbody_comm_init) and is REFUSED with NBODY_ERR_INVALID when none is (the other ranks' positions would
+   be stale from the second step on). */
 int nbody_step(nbody_ctx *ctx, int32_t nsteps);
 
 /* Only the force phase (accelerations of the current positions), no integration. */
@@ -171,7 +176,9 @@ int nbody_profile_enable(nbody_ctx *ctx, int32_t on);
 int nbody_profile_read(nbody_ctx *ctx, int32_t which, double *total_ms, int64_t *launches);
 int nbody_profile_reset(nbody_ctx *ctx);
 /* Duration in ms of every launch of that class since the last reset, in launch order: copies at most cap values,
-   returns how many there are (< 0: error).  Lets a harness report min/median/max, not only the mean. */
+   returns how many there are (< 0: error).  Lets a harness report min/median/max, not only the mean.  The library
+   keeps the most recent 32 768 - 65 536 samples per class (older ones are dropped, so a host that leaves profiling on
+   for days does not grow); totals and launch counts of nbody_profile_read are not affected. */
 int64_t nbody_profile_samples(nbody_ctx *ctx, int32_t which, float *out_ms, int64_t cap);
 
 /* Introspection for tests/bench: which force variant upload selected (1..4), grid geometry. */
@@ -200,7 +207,10 @@ int nbody_bh_group_counters(nbody_ctx *ctx, int32_t *visits, int32_t *accepts);
    returns without synchronising.  It calls no hipMalloc/hipFree: the j-slice partial sums and the per-body clamp
    constants live in a 33.8 MB array that the library holds statically on every GPU it runs on.  Limits:
    num_bodies <= 65536 (NBODY_ERR_INVALID beyond); all calls on one GPU share that array, so calls that overlap on
-   one GPU (different streams, different threads) race — serialise them. */
+   one GPU (different streams, different threads) race — serialise them.  The FIRST call on a GPU resolves the
+   array's address (hipGetSymbolAddress, which may load the code object): make one warm-up call per GPU OUTSIDE any
+   stream capture; every later call only enqueues kernels and can be captured (tests/test_zz_no_alloc.py replays it
+   from a hipGraph).  The launch plan honours the same developer knobs (NBODY_FORCE_K/SLICES/TILE) as a context's. */
 int nbody_accel_noalloc(int32_t num_bodies, const float *dev_m, const float *dev_posX, const float *dev_posY,
                         const float *dev_radius, float *dev_accX, float *dev_accY, void *hip_stream);
 

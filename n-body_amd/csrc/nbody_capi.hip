@@ -60,6 +60,14 @@ constexpr float kBhSortedThetaScale = 0.6f;     // tools/bh_sorted_scale.py, pro
 constexpr int kBhQuadMaxGroups = 6144;      // four waves per group (bh_walk_quad_kernel) up to 49 152 targets at theta >= 1 ...
 constexpr int kBhQuadMinGroups = 3072;      // ... 24 576 at theta <= 0.5, linear in between (measured crossovers)
 constexpr size_t kMaxEventsPerClass = 4096;
+constexpr size_t kMaxSamplesPerClass = 1 << 16;   // nbody_profile_samples keeps the most recent 32 768 .. 65 536 launches
+
+// a long-running host that leaves profiling on must not grow without bound: drop the older half when full
+void push_sample(std::vector<float>& v, float ms)
+{
+    if (v.size() >= kMaxSamplesPerClass) v.erase(v.begin(), v.begin() + (std::ptrdiff_t)(kMaxSamplesPerClass / 2));
+    v.push_back(ms);
+}
 
 }  // namespace
 
@@ -149,7 +157,7 @@ int profile_begin(nbody_ctx* ctx, int cls, EventPair** out)
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, p.pool[cls][i].a, p.pool[cls][i].b));
             p.total_ms[cls] += ms;
-            p.samples[cls].push_back(ms);
+            push_sample(p.samples[cls], ms);
         }
         p.used[cls] = 0;
     }
@@ -263,7 +271,9 @@ int enqueue_bh_build(nbody_ctx* ctx)
     bh_keys_kernel<<<grid_n, blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr, ctx->cfg.spread, adaptive ? 0 : 1, b.keys, b.vals, b.tie,
                                           b.gkeys, b.gvals, b.gcap, b.tie_table, b.tie_table_size, fused ? 1 : 0, ctx->m, b.body4);
     const char* rank_env = std::getenv("NBODY_BH_RANKSORT_MAX");         // developer/test switch
-    const bool ranked = fused && n <= (rank_env ? std::atoi(rank_env) : kBhRankSortMax);
+    // (the rank buffers exist only up to kBhRankSortMax bodies, nbody_create: the knob can lower the limit, never raise it)
+    const int rank_max = rank_env ? (std::atoi(rank_env) < kBhRankSortMax ? std::atoi(rank_env) : kBhRankSortMax) : kBhRankSortMax;
+    const bool ranked = fused && b.rank != nullptr && n <= rank_max;
     if (ranked) {
         // small N: rank by brute-force counting, one launch.  ~1024 workgroups: i-tiles of 256 x j-slices
         const int tiles = (int)grid_n.x;
@@ -403,11 +413,10 @@ ForcePlan make_force_plan(int n, int nt, int variant, int max_slices, int k_req 
     return p;
 }
 
-void plan_force(nbody_ctx* ctx)
+// the plan a context of this shape gets, developer knobs included (shared with nbody_accel_noalloc, whose results are
+// promised to be the context's bit for bit: same slices, same summation order)
+ForcePlan make_force_plan_env(int n, int nt, int variant, int fused_cap = 0)
 {
-    const int n = ctx->cfg.num_bodies;
-    const int nt = ctx->i_end - ctx->i_begin;
-    const int variant = ctx->variant ? ctx->variant : (int)kScaled;
     // developer tuning knobs (not part of the ABI): NBODY_FORCE_K = 2|4, NBODY_FORCE_SLICES = 1..64,
     // NBODY_FORCE_TILE = small|big
     int k = 0, want = 0, tile = 0;
@@ -420,7 +429,16 @@ void plan_force(nbody_ctx* ctx)
         if (v >= 1 && v <= kMaxSlices) want = v;
     }
     if (const char* e = std::getenv("NBODY_FORCE_TILE")) tile = (e[0] == 's') ? kTileSmall : big_tile_of(variant);
-    const ForcePlan p = make_force_plan(n, nt, variant, kMaxSlices, k, want, tile);
+    (void)fused_cap;
+    return make_force_plan(n, nt, variant, kMaxSlices, k, want, tile);
+}
+
+void plan_force(nbody_ctx* ctx)
+{
+    const int n = ctx->cfg.num_bodies;
+    const int nt = ctx->i_end - ctx->i_begin;
+    const int variant = ctx->variant ? ctx->variant : (int)kScaled;
+    const ForcePlan p = make_force_plan_env(n, nt, variant);
     ctx->k_per_lane = p.k;
     ctx->blocks_x = p.blocks_x;
     ctx->tile = p.tile;
@@ -798,17 +816,30 @@ int nbody_step(nbody_ctx* ctx, int32_t nsteps)
     if (!ctx->uploaded) return fail(NBODY_ERR_INVALID, "nbody_step: nbody_upload has not been called");
     if (nsteps < 0) return fail(NBODY_ERR_INVALID, "nbody_step: nsteps=%d", nsteps);
     HIP_TRY(hipSetDevice(ctx->device));
-    if (nsteps > 0 && ensure_step_graph(ctx)) {
-        for (int s = 0; s < nsteps; ++s) {
-            HIP_TRY(hipGraphLaunch(ctx->step_graph, ctx->stream));
-            ++ctx->steps_enqueued;
-        }
-        return NBODY_OK;
-    }
+    // A context that owns only part of the bodies advances only those: after ONE step every other body's position is
+    // stale until the owners' slices have been exchanged.  Several steps in one call are therefore either refused or,
+    // with a communicator attached (nbody_comm_init), run as nsteps x (step + nbody_exchange_positions).
+    const int n = ctx->cfg.num_bodies;
+    const bool partial = ctx->cfg.shard_begin != 0 || (ctx->cfg.shard_count != 0 && ctx->cfg.shard_count != n);
+    if (partial && nsteps > 1 && !ctx->comm)
+        return fail(NBODY_ERR_INVALID, "nbody_step: nsteps=%d on a context that owns only bodies [%d,+%d) of %d: the other bodies' "
+                                       "positions would be stale after the first step.  Call nbody_step(ctx, 1) and exchange posX/posY "
+                                       "between steps, or attach a communicator (nbody_comm_init)",
+                    nsteps, ctx->cfg.shard_begin, ctx->cfg.shard_count, n);
+    const bool exchange_each = partial && nsteps > 1;       // (a single step leaves the exchange to the caller, as before)
+    const bool graph = nsteps > 0 && ensure_step_graph(ctx);
     for (int s = 0; s < nsteps; ++s) {
-        const int rc = enqueue_one_step(ctx);
-        if (rc) return rc;
+        if (graph) {
+            HIP_TRY(hipGraphLaunch(ctx->step_graph, ctx->stream));
+        } else {
+            const int rc = enqueue_one_step(ctx);
+            if (rc) return rc;
+        }
         ++ctx->steps_enqueued;
+        if (exchange_each) {
+            const int rc = nbody_exchange_positions(ctx);
+            if (rc) return rc;
+        }
     }
     return NBODY_OK;
 }
@@ -992,7 +1023,7 @@ int nbody_profile_read(nbody_ctx* ctx, int32_t which, double* total_ms, int64_t*
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, p.pool[which][i].a, p.pool[which][i].b));
         p.total_ms[which] += ms;
-        p.samples[which].push_back(ms);
+        push_sample(p.samples[which], ms);
     }
     p.used[which] = 0;
     if (total_ms) *total_ms = p.total_ms[which];
@@ -1162,7 +1193,7 @@ int nbody_accel_noalloc(int32_t num_bodies, const float* dev_m, const float* dev
     const int lim = n - n % 8;                                   // benchmark.cpp:423: the N%8 tail is never a target
     if (lim > 0) {
         const int stride = ((lim + 63) / 64) * 64;
-        const ForcePlan p = make_force_plan(n, lim, kExact, kMaxSlices);
+        const ForcePlan p = make_force_plan_env(n, lim, kExact);   // = plan_force of the equivalent context
         if ((size_t)n + 2 * (size_t)p.slices * stride > kNoAllocScratchFloats)
             return fail(NBODY_ERR_INVALID, "nbody_accel_noalloc: internal: plan exceeds the scratch array");
         float* c = sp;                                           // [n]

@@ -4,7 +4,10 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 this package, and only as the checker.  The product package (``n-body_amd``) never does.
 
 * ``libnbody_oracle.so``      — oracle/nbody_oracle.c, the plain-C restatement.
-* ``_ref/libnbody_ref.so``    — /root/reference/benchmark.cpp itself, compiled by build_ref.sh.
+* ``_ref/libnbody_ref.so``    — /root/reference/benchmark.cpp itself, compiled by build_ref.sh; nothing added inside its
+  hot loops: every TIMING of the reference goes through this one.
+* ``_ref/libnbody_ref_counted.so`` — the same with per-group vote counters inside the walk (benchmark.cpp:245, 267);
+  only ``ref_run(..., count_votes=True)`` loads it (vote-parity tests), never a timing.
 """
 import ctypes as C
 import os
@@ -14,6 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(_HERE, "libnbody_oracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libnbody_ref.so")
+REF_COUNTED_SO = os.path.join(_HERE, "_ref", "libnbody_ref_counted.so")   # the same + vote counters inside the walk
 REF_MAINPHYS_SO = os.path.join(_HERE, "_ref", "libnbody_ref_mainphys.so")       # main.cpp's physics block (485-642)
 REF_DROPIN_SO = os.path.join(_HERE, "_ref", "libnbody_ref_dropin.so")   # same file, physics block -> include/nbody.h
 
@@ -248,11 +252,16 @@ class _RefIO(C.Structure):
 
 
 _ref = None
+_ref_counted = None
 _ref_dropin = None
 
 
 def ref_available():
     return os.path.exists(REF_SO)
+
+
+def ref_counted_available():
+    return os.path.exists(REF_COUNTED_SO)
 
 
 def ref_dropin_available():
@@ -271,7 +280,7 @@ def _fp(a):
 
 
 def ref_run(n, *, use_barnes_hut, nsteps, bodies=None, seed=12345, spread=400.0, mass=1000.0, theta=1.0,
-            dt=0.05, use_parallel=1, want_pool=False, dropin=False, main_cpp=False):
+            dt=0.05, use_parallel=1, want_pool=False, dropin=False, main_cpp=False, count_votes=False):
     """Run the compiled reference loop (benchmark.cpp:349-557) for nsteps.
 
     bodies=None -> the reference's own generator (benchmark.cpp:317-339) with `seed`.
@@ -279,8 +288,13 @@ def ref_run(n, *, use_barnes_hut, nsteps, bodies=None, seed=12345, spread=400.0,
     of benchmark.cpp's.
     dropin=True -> the DROP-IN build: the same reference program with its physics block replaced by the C-ABI
     (needs a GPU; tree read-back fields stay empty).
+    count_votes=True -> the COUNTED build (libnbody_ref_counted.so): per-group visit/accept counters and the hash of the
+    accepted nodes from inside the reference's walk.  The default runs libnbody_ref.so, whose walk carries no probe and
+    whose RefIO counter pointers stay NULL: that is the one to time (the counters cost 3-7x at N >= 2e5).
     Returns dict(init=Bodies, final=Bodies, acc=(ax, ay) of the last step, nodes_used, root, pool, step_ms)."""
-    global _ref, _ref_dropin, _ref_mainphys
+    global _ref, _ref_counted, _ref_dropin, _ref_mainphys
+    if count_votes and (main_cpp or dropin or not use_barnes_hut):
+        raise ValueError("count_votes=True is for benchmark.cpp's own Barnes-Hut walk only")
     if main_cpp:
         if bodies is None:
             raise ValueError("main_cpp=True needs bodies (main.cpp's generator sits behind its SFML code)")
@@ -295,9 +309,19 @@ def ref_run(n, *, use_barnes_hut, nsteps, bodies=None, seed=12345, spread=400.0,
             _ref_dropin.ref_benchmark_run_dropin.argtypes = [C.POINTER(_RefIO)]
             _ref_dropin.ref_benchmark_run_dropin.restype = C.c_int
         entry = _ref_dropin.ref_benchmark_run_dropin
+    elif count_votes:
+        if _ref_counted is None:
+            _ref_counted = C.CDLL(REF_COUNTED_SO)
+            _ref_counted.ref_benchmark_run.argtypes = [C.POINTER(_RefIO)]
+            _ref_counted.ref_benchmark_run.restype = C.c_int
+            if _ref_counted.ref_votes_counted() != 1:
+                raise RuntimeError(f"{REF_COUNTED_SO} was built without REF_COUNT_VOTES")
+        entry = _ref_counted.ref_benchmark_run
     else:
         if _ref is None:
             _ref = C.CDLL(REF_SO)
+            if _ref.ref_votes_counted() != 0:
+                raise RuntimeError(f"{REF_SO} carries the vote counters: timings of it would not be the reference's")
             _ref.ref_benchmark_run.argtypes = [C.POINTER(_RefIO)]
             _ref.ref_benchmark_run.restype = C.c_int
         entry = _ref.ref_benchmark_run
@@ -333,7 +357,7 @@ def ref_run(n, *, use_barnes_hut, nsteps, bodies=None, seed=12345, spread=400.0,
     groups = max(n // 8, 1)
     gv = np.zeros(groups, np.int32); ga = np.zeros(groups, np.int32); gh = np.zeros(groups, np.uint64)
     sv = np.zeros(max(nsteps, 1), np.int64); sa = np.zeros(max(nsteps, 1), np.int64)
-    if use_barnes_hut and not main_cpp and not dropin:
+    if count_votes:
         io.grp_visits = gv.ctypes.data_as(C.POINTER(C.c_int))
         io.grp_accepts = ga.ctypes.data_as(C.POINTER(C.c_int))
         io.grp_hash = gh.ctypes.data_as(C.POINTER(C.c_ulonglong))
@@ -347,12 +371,17 @@ def ref_run(n, *, use_barnes_hut, nsteps, bodies=None, seed=12345, spread=400.0,
     final.radius[:] = srcb.radius
     if pool is not None:
         pool = pool[:used.value].copy()
-    return dict(init=init, final=final, acc=(ax, ay), nodes_used=used.value, root=root, pool=pool,
-                step_ms=ms[:nsteps],
-                # the reference's own vote (benchmark.cpp:242-276): per group of 8, accumulated over the nsteps of this
-                # run, and the totals of every step
-                grp_visits=gv[:n // 8], grp_accepts=ga[:n // 8], grp_hash=gh[:n // 8],
-                step_visits=sv[:nsteps], step_accepts=sa[:nsteps])
+    out = dict(init=init, final=final, acc=(ax, ay), nodes_used=used.value, root=root, pool=pool, step_ms=ms[:nsteps],
+               counted=bool(count_votes),
+               # what the call handed to the library (tests assert that a timing call hands over NULL)
+               counter_pointers_null=not any(bool(getattr(io, k)) for k in
+                                             ("grp_visits", "grp_accepts", "grp_hash", "step_visits", "step_accepts")))
+    if count_votes:
+        # the reference's own vote (benchmark.cpp:242-276): per group of 8, accumulated over the nsteps of this
+        # run, and the totals of every step
+        out.update(grp_visits=gv[:n // 8], grp_accepts=ga[:n // 8], grp_hash=gh[:n // 8],
+                   step_visits=sv[:nsteps], step_accepts=sa[:nsteps])
+    return out
 
 
 # ---------------------------------------------------------------------------------------------

@@ -30,6 +30,9 @@ if [ "$GOT" != "$PIN" ]; then
 fi
 mkdir -p "$OUT_DIR"
 
+# $1 = output stem, $2 = extra compiler flag ("" or -DREF_COUNT_VOTES: see ref_hooks.h)
+build_reference() {
+local stem="$1" extra="$2"
 awk '
 function expect(re) { if ($0 !~ re) { printf("build_ref: line %d does not match /%s/: %s\n", NR, re, $0) > "/dev/stderr"; bad = 1 } }
 NR==72  { expect("private:");                 print "public:"; next }
@@ -56,12 +59,18 @@ NR==559 { expect("logFile.is_open");          print "    REF_AFTER_LOOP(data);";
 { print }
 END { if (bad) exit 3 }
 ' "$REF_SRC" | g++ -std=c++17 -O3 -march=x86-64-v3 -ffast-math -mavx2 -mfma -fopenmp -DNDEBUG \
-    -fPIC -c -include "$HERE/ref_hooks.h" -x c++ - -o "$OUT_DIR/nbody_ref.o"
+    -fPIC -c $extra -include "$HERE/ref_hooks.h" -x c++ - -o "$OUT_DIR/$stem.o"
 # Link WITHOUT -ffast-math: with it GCC links crtfastmath.o, whose constructor flips the whole
 # host process (numpy, the test runner) into FTZ/DAZ the moment the library is loaded.
-g++ -shared -fopenmp "$OUT_DIR/nbody_ref.o" -o "$OUT_DIR/libnbody_ref.so" -lpthread
-rm -f "$OUT_DIR/nbody_ref.o"
-echo "build_ref: built $OUT_DIR/libnbody_ref.so"
+g++ -shared -fopenmp "$OUT_DIR/$stem.o" -o "$OUT_DIR/lib$stem.so" -lpthread
+rm -f "$OUT_DIR/$stem.o"
+echo "build_ref: built $OUT_DIR/lib$stem.so"
+
+}
+# libnbody_ref.so: the reference, unprobed inside its walk (benchmark.cpp:242-276 untouched) - what every timing uses.
+# libnbody_ref_counted.so: the same with the per-group vote counters at benchmark.cpp:245/267 - what the vote-parity tests use.
+build_reference nbody_ref ""
+build_reference nbody_ref_counted "-DREF_COUNT_VOTES"
 
 # ---- drop-in build: the same file with INTEGRATION.md's edit applied (physics -> include/nbody.h on the GPU) ----
 # Same compiler flags as above, so that the generator and the harness are the same machine code in both builds.

@@ -52,6 +52,12 @@ static int *g_ref_grp_visits = nullptr, *g_ref_grp_accepts = nullptr;
 static unsigned long long *g_ref_grp_hash = nullptr;
 static long long g_ref_prev_visits = 0, g_ref_prev_accepts = 0;
 
+/* The two hooks below sit INSIDE the reference's hot loop (benchmark.cpp:242-276).  They exist only in the COUNTED
+   build (oracle/_ref/libnbody_ref_counted.so, -DREF_COUNT_VOTES), which the vote-parity tests use; in
+   libnbody_ref.so — the library every TIMING of the reference goes through (bench.py cpu_baseline*, tools/dropin_time.py)
+   — they expand to nothing, so the walk is the reference's own machine code, unprobed (the per-group
+   counters, 16 groups to a cache line under schedule(dynamic), made the Barnes-Hut step 3-7x slower). */
+#ifdef REF_COUNT_VOTES
 /* after node_stack.pop_back(), benchmark.cpp:245 */
 #define REF_VISIT(start) do { if (g_ref_grp_visits) ++g_ref_grp_visits[(start) >> 3]; } while (0)
 /* inside the accept branch, benchmark.cpp:267 */
@@ -59,6 +65,15 @@ static long long g_ref_prev_visits = 0, g_ref_prev_accepts = 0;
     do { if (g_ref_grp_accepts) ++g_ref_grp_accepts[(start) >> 3];                                      \
          if (g_ref_grp_hash) g_ref_grp_hash[(start) >> 3] =                                             \
              (g_ref_grp_hash[(start) >> 3] ^ (unsigned long long)(unsigned)(node)) * 1099511628211ull; } while (0)
+#define REF_VOTES_COUNTED 1
+#else
+#define REF_VISIT(start) do { } while (0)
+#define REF_ACCEPT(start, node) do { } while (0)
+#define REF_VOTES_COUNTED 0
+#endif
+/* 1 when this library was built with the counters (the Python side refuses to ask an uncounted build for them) */
+extern "C" int ref_votes_counted(void);
+int ref_votes_counted(void) { return REF_VOTES_COUNTED; }
 
 #define REF_CP_IN(dst, src)  do { if (src) std::memcpy((dst).data(), (src), sizeof(float) * (size_t)p->n); } while (0)
 #define REF_CP_OUT(dst, src) do { if (dst) std::memcpy((dst), (src).data(), sizeof(float) * (size_t)p->n); } while (0)

@@ -37,8 +37,8 @@ def naive_case(n, nsteps_final, dt=0.05):
 
 
 def bh_case(n, theta, nsteps_final, dt=0.05, want_pool=False):
-    r1 = O.ref_run(n, use_barnes_hut=1, nsteps=1, seed=SEED, dt=dt, theta=theta, want_pool=want_pool)
-    rk = O.ref_run(n, use_barnes_hut=1, nsteps=nsteps_final, seed=SEED, dt=dt, theta=theta)
+    r1 = O.ref_run(n, use_barnes_hut=1, nsteps=1, seed=SEED, dt=dt, theta=theta, want_pool=want_pool, count_votes=True)
+    rk = O.ref_run(n, use_barnes_hut=1, nsteps=nsteps_final, seed=SEED, dt=dt, theta=theta, count_votes=True)
     init = r1["init"]
     out = dict(n=n, seed=SEED, spread=400.0, mass=1000.0, dt=dt, theta=theta, nsteps_final=nsteps_final,
                m=init.m[:1].copy(), radius=init.radius[:1].copy(),
@@ -65,7 +65,7 @@ def close_pair_case():
     b.posX[7], b.posY[7] = np.float32(0.5), np.float32(0.25)
     b.posX[100], b.posY[100] = np.nextafter(np.float32(0.5), np.float32(1), dtype=np.float32), np.float32(0.25)
     b.posX[100] = np.nextafter(b.posX[100], np.float32(1), dtype=np.float32)          # 2 ulp = 1.2e-7
-    r1 = O.ref_run(n, use_barnes_hut=1, nsteps=1, bodies=b, theta=1.0, want_pool=True)
+    r1 = O.ref_run(n, use_barnes_hut=1, nsteps=1, bodies=b, theta=1.0, want_pool=True, count_votes=True)
     depth = 0
     pool = r1["pool"]
     stack = [(0, 0)]

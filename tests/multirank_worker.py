@@ -14,7 +14,8 @@ import __graft_entry__ as entry  # noqa: E402
 
 def main():
     import faulthandler
-    faulthandler.dump_traceback_later(60, exit=True)     # a stalled rank reports where it stands and ends
+    # a stalled rank reports where it stands and ends (NBODY_DEBUG_TIMEOUT: seconds, as in bench.py; a busy box may need more)
+    faulthandler.dump_traceback_later(int(os.environ.get("NBODY_DEBUG_TIMEOUT", "60")), exit=True)
     n, nsteps, bh = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     out = sys.argv[4]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])

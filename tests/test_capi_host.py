@@ -20,7 +20,7 @@ def test_header_symbols_all_exported(nb):
     raw = C.CDLL(nb.LIB_PATH)
     for s in declared:
         assert hasattr(raw, s), f"{s} declared in include/nbody.h but not exported"
-    assert nb.lib().nbody_abi_version() == 1
+    assert nb.lib().nbody_abi_version() == int(re.search(r"#define NBODY_ABI_VERSION (\d+)", hdr).group(1)) >= 2
 
 
 def test_default_config_matches_reference_literals(nb):

@@ -100,10 +100,10 @@ def test_vote_of_the_reference_on_this_host(nb, O, n, theta):
     """The reference's vote goes through vrcpps, whose bits are CPU-vendor specific: the goldens were
     made on the build container's Intel host.  This runs the compiled reference on THIS box's host CPU (N = 65 536,
     and BASELINE config 4's full N = 10^6 at both thetas) and compares its per-group counters with the GPU walk's."""
-    if not O.ref_available():
-        pytest.skip("oracle/_ref/libnbody_ref.so not built")
+    if not O.ref_counted_available():
+        pytest.skip("oracle/_ref/libnbody_ref_counted.so not built")
     b = O.init_disc(n, seed=777)
-    r = O.ref_run(n, use_barnes_hut=1, nsteps=1, bodies=b, theta=theta)
+    r = O.ref_run(n, use_barnes_hut=1, nsteps=1, bodies=b, theta=theta, count_votes=True)
     _, _, _, _, cnt = gpu_bh(nb, b, theta=theta, want_groups=True)
     v, a = cnt["groups"]
     differ = int(((v != r["grp_visits"]) | (a != r["grp_accepts"])).sum())

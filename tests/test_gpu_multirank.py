@@ -71,3 +71,58 @@ def test_bench_two_ranks_prints_one_json_line(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong" and d["value"] > 0
     assert "cpu_baseline" not in d            # rank 0 at N=1 only
     assert d["config"]["num_bodies"] == 131072
+
+
+def test_bench_gpus_2_from_a_plain_interpreter_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run around it: bench.py starts the two
+    ranks itself as fresh children before anything touches the GPU, relays rank 0's one JSON line and the exit code."""
+    import json
+    env = dict(os.environ, NBODY_DIST_BACKEND="gloo", OMP_NUM_THREADS="2", NBODY_LAUNCH_TIMEOUT="140")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--bodies", "65536"]
+    r = launch(cmd, env, 170, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["config"]["num_bodies"] == 65536
+
+
+def test_bench_self_launch_propagates_a_failing_rank(tmp_path):
+    """A rank that dies (here: an argument bench.py rejects) must surface as a non-zero exit code of the launcher."""
+    env = dict(os.environ, NBODY_DIST_BACKEND="gloo", OMP_NUM_THREADS="2", NBODY_LAUNCH_TIMEOUT="120")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--bodies", "0"]
+    r = launch(cmd, env, 150, cwd=str(tmp_path))
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_several_steps_on_a_partial_shard_are_refused_without_a_communicator(nb, O):
+    """nbody_step(ctx, n > 1) on a context that owns part of the bodies would advance with stale remote positions
+    (VERDICT r2 item 2): NBODY_ERR_INVALID unless a communicator is attached; n = 1 and whole-range contexts unchanged."""
+    n = 4096
+    b = O.init_disc(n, seed=5)
+    with nb.NBodySim(n, dt=0.05, useBarnesHut=False, shard=nb.shard_range(n, 2, 1)) as sim:
+        sim.upload(*b.arrays())
+        sim.step(1)
+        with pytest.raises(nb.NBodyError) as e:
+            sim.step(2)
+        assert e.value.code == nb.ERR_INVALID and "stale" in str(e.value)
+        sim.step(1).sync()
+    with nb.NBodySim(n, dt=0.05, useBarnesHut=False, shard=(0, n)) as sim:      # the whole range spelled out: not partial
+        sim.upload(*b.arrays())
+        sim.step(3).sync()
+    # with a (1-rank) communicator attached the same call runs step + exchange n times
+    with nb.NBodySim(n, dt=0.05, useBarnesHut=False) as one, nb.NBodySim(n, dt=0.05, useBarnesHut=False) as ref:
+        try:
+            one.comm_init(0, 1, nb.comm_unique_id())
+        except nb.NBodyError as e:
+            if e.code == nb.ERR_UNSUPPORTED:
+                pytest.skip("RCCL not loadable on this box")
+            raise
+        one.upload(*b.arrays()); ref.upload(*b.arrays())
+        one.step(3).sync(); ref.step(3).sync()
+        assert all(np.array_equal(one.download()[k], ref.download()[k]) for k in ("posX", "posY", "velX", "velY"))

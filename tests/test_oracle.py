@@ -192,11 +192,11 @@ def test_reference_vote_totals_per_step(O, name):
 def test_reference_vote_live_if_present(O):
     """Same census against the reference RUN ON THIS HOST (its vrcpps bits are CPU-vendor specific):
     N = 65 536, theta = 1 — 5.1e6 group-visits."""
-    if not O.ref_available():
-        pytest.skip("oracle/_ref/libnbody_ref.so not built")
+    if not O.ref_counted_available():
+        pytest.skip("oracle/_ref/libnbody_ref_counted.so not built")
     n = 65536
     b = O.init_disc(n, seed=777)
-    r = O.ref_run(n, use_barnes_hut=1, nsteps=1, bodies=b, theta=1.0)
+    r = O.ref_run(n, use_barnes_hut=1, nsteps=1, bodies=b, theta=1.0, count_votes=True)
     v, a, h = O.Tree(n).build(b, 400.0).group_counters(b, 1.0)
     differ = int(((v != r["grp_visits"]) | (a != r["grp_accepts"]) | (h != r["grp_hash"])).sum())
     assert differ == 0, f"{differ} of {n // 8} groups differ"
@@ -285,3 +285,35 @@ def test_main_cpp_physics_vs_benchmark_cpp_physics(O, bh, n):
         for f in ("tlX", "tlY", "brX", "brY", "bodyIndex", "children", "mass", "comX", "comY"):
             assert np.array_equal(pool[f], main["pool"][f]), f
         assert not (np.array_equal(main["pool"]["comX"], bench["pool"]["comX"]) and np.array_equal(main["pool"]["comY"], bench["pool"]["comY"]))
+
+
+def test_a_timing_call_runs_the_unprobed_reference(O, monkeypatch):
+    """the Barnes-Hut CPU baseline must be the reference, not the reference plus a probe.  A default
+    ref_run (what bench.py's cpu_baseline*, tools/dropin_time.py and tools/bh_time.py call) goes to libnbody_ref.so,
+    which is built WITHOUT the counter hooks at benchmark.cpp:245/267, and hands over NULL counter arrays; only
+    count_votes=True reaches the counted library.  Both builds give the same physics."""
+    if not (O.ref_available() and O.ref_counted_available()):
+        pytest.skip("oracle/_ref not built")
+    n = 4096
+    b = O.init_disc(n, seed=99)
+    plain = O.ref_run(n, use_barnes_hut=1, nsteps=2, bodies=b, theta=1.0)
+    assert plain["counter_pointers_null"] and not plain["counted"] and "grp_visits" not in plain
+    assert O._ref.ref_votes_counted() == 0
+    counted = O.ref_run(n, use_barnes_hut=1, nsteps=2, bodies=b, theta=1.0, count_votes=True)
+    assert not counted["counter_pointers_null"] and counted["counted"] and int(counted["step_visits"][0]) > 0
+    assert O._ref_counted.ref_votes_counted() == 1
+    for k in ("posX", "posY", "velX", "velY"):
+        assert np.array_equal(getattr(plain["final"], k), getattr(counted["final"], k))
+    with pytest.raises(ValueError):
+        O.ref_run(n, use_barnes_hut=0, nsteps=1, bodies=b, count_votes=True)
+    # bench.py's Barnes-Hut baseline leg: spy on the call it makes
+    import bench
+    seen = {}
+    real = O.ref_run
+
+    def spy(*a, **kw):
+        seen.update(kw)
+        return real(*a, **kw)
+    monkeypatch.setattr(O, "ref_run", spy)
+    out = bench.cpu_baseline_bh(2048, 1.0)
+    assert out["kind"] == "reference" and not seen.get("count_votes", False)

@@ -71,3 +71,30 @@ def test_rejects_sizes_beyond_the_static_array(nb):
     assert e.value.code == nb.ERR_INVALID and "65536" in str(e.value)
     with pytest.raises(nb.NBodyError):
         nb.accel_noalloc(1024, 0, 8, 8, 8, 8, 8)
+
+
+def test_captured_into_a_graph_and_replayed(nb, O):
+    """The caller the entry point is for: a stream capture.  After one warm-up call outside the capture (it resolves the
+    static array's address on this GPU), the call is captured into a graph — nothing in it allocates, synchronises or
+    is otherwise illegal under capture — and the graph is replayed on new inputs written into the same buffers."""
+    import torch
+    torch.cuda.set_device(0)
+    a, b2 = O.init_disc(4099, seed=21), O.init_disc(4099, seed=22)
+    n = a.n
+    m, px, py, r = (_dev(torch, x) for x in (a.m, a.posX, a.posY, a.radius))
+    ax = torch.zeros(n, device="cuda"); ay = torch.zeros(n, device="cuda")
+    s = torch.cuda.Stream()
+    nb.accel_noalloc(n, m.data_ptr(), px.data_ptr(), py.data_ptr(), r.data_ptr(), ax.data_ptr(), ay.data_ptr(), s.cuda_stream)
+    s.synchronize()                                          # warm-up, outside the capture
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+        nb.accel_noalloc(n, m.data_ptr(), px.data_ptr(), py.data_ptr(), r.data_ptr(), ax.data_ptr(), ay.data_ptr(),
+                         torch.cuda.current_stream().cuda_stream)
+    for bodies in (a, b2, a):
+        px.copy_(_dev(torch, bodies.posX)); py.copy_(_dev(torch, bodies.posY))
+        ax.fill_(float("nan")); ay.fill_(float("nan"))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        cx, cy = _context(nb, bodies)
+        assert np.array_equal(ax.cpu().numpy(), cx) and np.array_equal(ay.cpu().numpy(), cy)

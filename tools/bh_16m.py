@@ -9,7 +9,7 @@ nb = e.load_package(); O = e.load_oracle()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 24
 theta = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
 world = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-srt = "--sorted" in sys.argv          # bh_sorted: compact groups, vote at 0.7 theta (ref_compat 0)
+srt = "--sorted" in sys.argv          # bh_sorted: compact groups, vote at 0.6 theta (ref_compat 0)
 t0 = time.time(); b = O.init_plummer(n, scale=50.0, seed=12345); print(f"plummer init {time.time()-t0:.1f}s", flush=True)
 inside = (np.abs(b.posX) <= 400) & (np.abs(b.posY) <= 400)
 print(f"bodies inside the root box: {inside.mean()*100:.1f}%", flush=True)

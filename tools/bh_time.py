@@ -8,7 +8,7 @@ nb = e.load_package()
 from nbody_amd import initial_conditions as ic
 O = e.load_oracle() if "--no-ref" not in sys.argv else None      # the compiled reference, timed beside the GPU
 fast = "--fast" in sys.argv
-srt = "--sorted" in sys.argv          # bh_sorted: compact groups, vote at 0.7 theta (ref_compat 0)
+srt = "--sorted" in sys.argv          # bh_sorted: compact groups, vote at 0.6 theta (ref_compat 0)
 for n, theta in ((10000, 1.0), (65536, 1.0), (1_000_000, 1.0), (1_000_000, 0.5)):
     b = ic.disc(n, seed=12345)
     sim = nb.NBodySim(n, theta=theta, useBarnesHut=True, bh_fast_math=fast, **(dict(bh_sorted=True, ref_compat=0) if srt else {})); sim.upload(*b)

@@ -23,7 +23,7 @@ print("N theta groups ref_visits ref_accepts oracle_visits oracle_accepts groups
 for n, theta in cases:
     b = O.init_disc(n, seed=12345)
     t0 = time.time()
-    r = O.ref_run(n, use_barnes_hut=1, nsteps=1, bodies=b, theta=theta)
+    r = O.ref_run(n, use_barnes_hut=1, nsteps=1, bodies=b, theta=theta, count_votes=True)
     v, a, h = O.Tree(n).build(b, 400.0).group_counters(b, theta)
     differ = int(((v != r["grp_visits"]) | (a != r["grp_accepts"]) | (h != r["grp_hash"])).sum())
     print(n, theta, n // 8, int(r["step_visits"][0]), int(r["step_accepts"][0]), int(v.sum()), int(a.sum()), differ,
