@@ -107,6 +107,40 @@ __device__ __forceinline__ f2 pair_weight(const f2 d2, const f2 ci, const Src<V>
     }
 }
 
+// kScaled, a whole inner iteration at once: w[g] = clamp(inv[g]^2) for G packed pairs in ONE asm statement.  The wait
+// state a VALU read of a fresh v_rsq_f32 result needs (see pair_weight) can only concern the FIRST multiply — every
+// later one has at least one instruction between it and the last v_rsq_f32, which the compiler can only have placed
+// before the statement — so one s_nop serves the block instead of one per multiply (round 2: 8 per iteration, priced at
+// 0.7 % by profiles/r1_clamp_variants_ab.txt).  Outputs are early-clobber: w[0] is written while inv[1..] are unread.
+#ifndef NBODY_CLAMP_BLOCK
+#define NBODY_CLAMP_BLOCK 1
+#endif
+template <int G> __device__ __forceinline__ void clamp_square_block(const f2 (&inv)[G], f2 (&w)[G]);
+template <> __device__ __forceinline__ void clamp_square_block<4>(const f2 (&inv)[4], f2 (&w)[4])
+{
+    asm("s_nop 0\n\t"
+        "v_pk_mul_f32 %0, %4, %4 clamp\n\t"
+        "v_pk_mul_f32 %1, %5, %5 clamp\n\t"
+        "v_pk_mul_f32 %2, %6, %6 clamp\n\t"
+        "v_pk_mul_f32 %3, %7, %7 clamp"
+        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+        : "v"(inv[0]), "v"(inv[1]), "v"(inv[2]), "v"(inv[3]));
+}
+template <> __device__ __forceinline__ void clamp_square_block<8>(const f2 (&inv)[8], f2 (&w)[8])
+{
+    asm("s_nop 0\n\t"
+        "v_pk_mul_f32 %0, %8, %8 clamp\n\t"
+        "v_pk_mul_f32 %1, %9, %9 clamp\n\t"
+        "v_pk_mul_f32 %2, %10, %10 clamp\n\t"
+        "v_pk_mul_f32 %3, %11, %11 clamp\n\t"
+        "v_pk_mul_f32 %4, %12, %12 clamp\n\t"
+        "v_pk_mul_f32 %5, %13, %13 clamp\n\t"
+        "v_pk_mul_f32 %6, %14, %14 clamp\n\t"
+        "v_pk_mul_f32 %7, %15, %15 clamp"
+        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
+        : "v"(inv[0]), "v"(inv[1]), "v"(inv[2]), "v"(inv[3]), "v"(inv[4]), "v"(inv[5]), "v"(inv[6]), "v"(inv[7]));
+}
+
 // grid = (ceil(n_targets / (kBlock*K)), j_slices).  Block b handles targets
 // i_begin + b*kBlock*K + k*kBlock + tid (lane-contiguous => coalesced) against the sources of slice y.
 // K targets per lane are held as K/2 packed pairs; JU sources are processed per inner iteration in
@@ -197,10 +231,19 @@ __global__ __launch_bounds__(kBlock, MINW) void force_naive_kernel(const ForceAr
             for (int g = 0; g < G; ++g) d2[g] = __builtin_elementwise_fma(dy[g], dy[g], tiny2);
 #pragma unroll
             for (int g = 0; g < G; ++g) d2[g] = __builtin_elementwise_fma(dx[g], dx[g], d2[g]);
+            if constexpr (V == kScaled && NBODY_CLAMP_BLOCK && (G == 4 || G == 8)) {
+                f2 inv[G], w[G];
 #pragma unroll
-            for (int u = 0; u < JU; ++u)
+                for (int g = 0; g < G; ++g) { inv[g].x = __builtin_amdgcn_rsqf(d2[g].x); inv[g].y = __builtin_amdgcn_rsqf(d2[g].y); }
+                clamp_square_block<G>(inv, w);
 #pragma unroll
-                for (int k = 0; k < KP; ++k) f[u * KP + k] = pair_weight<V>(d2[u * KP + k], C[k], s[u], a.uni_c);
+                for (int g = 0; g < G; ++g) f[g] = inv[g] * w[g];
+            } else {
+#pragma unroll
+                for (int u = 0; u < JU; ++u)
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) f[u * KP + k] = pair_weight<V>(d2[u * KP + k], C[k], s[u], a.uni_c);
+            }
 #pragma unroll
             for (int u = 0; u < JU; ++u)
 #pragma unroll

@@ -63,6 +63,9 @@ def test_two_calls_in_a_row_second_smaller(nb, O):
     ax, ay = _noalloc(nb, torch, third, stream=torch.cuda.Stream())
     cx, cy = _context(nb, third)
     assert np.array_equal(ax, cx) and np.array_equal(ay, cy)
+    # fewer than 8 bodies: nobody is a target (benchmark.cpp:423), the outputs are zeros
+    ax, ay = _noalloc(nb, torch, O.init_disc(5, seed=14))
+    assert not ax.any() and not ay.any()
 
 
 def test_rejects_sizes_beyond_the_static_array(nb):
