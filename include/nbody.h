@@ -23,9 +23,9 @@
 extern "C" {
 #endif
 
-/* 2: + nbody_upload_state, nbody_comm_plan, nbody_profile_samples, nbody_bh_group_counters, nbody_accel_noalloc,
+/* 3: + nbody_sort_pairs_u64 (round 3).  2: + nbody_upload_state, nbody_comm_plan, nbody_profile_samples, nbody_bh_group_counters, nbody_accel_noalloc,
       nbody_config.bh_sorted (was reserved[0]); nbody_step(ctx, n > 1) on a partial shard is refused / exchanges (round 3) */
-#define NBODY_ABI_VERSION 2
+#define NBODY_ABI_VERSION 3
 
 enum {
     NBODY_OK = 0,
@@ -213,6 +213,13 @@ int nbody_bh_group_counters(nbody_ctx *ctx, int32_t *visits, int32_t *accepts);
    from a hipGraph).  The launch plan honours the same developer knobs (NBODY_FORCE_K/SLICES/TILE) as a context's. */
 int nbody_accel_noalloc(int32_t num_bodies, const float *dev_m, const float *dev_posX, const float *dev_posY,
                         const float *dev_radius, float *dev_accX, float *dev_accY, void *hip_stream);
+
+/* Parity hook for the Barnes-Hut build's own device sort (csrc/bh_sort.hip.h; it replaces the order the reference gets
+   from serial insertion, benchmark.cpp:171-172): sorts n (key, value) pairs by key, STABLY, on the current device —
+   host arrays in and out, `repeats` sorts in a row on the same state (epochs, tickets and histograms carry over as
+   they do from build to build).  Not on any step path. */
+int nbody_sort_pairs_u64(const uint64_t *keys, const int32_t *vals, int32_t n, uint64_t *out_keys, int32_t *out_vals,
+                         int32_t repeats);
 
 const char *nbody_last_error(void); /* thread-local, never NULL */
 int nbody_abi_version(void);

@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "nbody_frame_acquire", "nbody_comm_unique_id", "nbody_comm_init", "nbody_exchange_positions", "nbody_comm_plan", "nbody_get_accel",
     "nbody_diagnostics", "nbody_device_ptr", "nbody_profile_enable", "nbody_profile_read",
     "nbody_profile_reset", "nbody_profile_samples", "nbody_get_info", "nbody_bh_tree_nodes", "nbody_bh_counters",
-    "nbody_bh_group_counters", "nbody_accel_noalloc",
+    "nbody_bh_group_counters", "nbody_accel_noalloc", "nbody_sort_pairs_u64",
     "nbody_last_error", "nbody_abi_version",
 )
 
@@ -90,6 +90,7 @@ def lib():
         L.nbody_bh_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.nbody_bh_group_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.nbody_accel_noalloc.argtypes = [C.c_int32] + [C.c_void_p] * 7
+        L.nbody_sort_pairs_u64.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
         L.nbody_last_error.restype = C.c_char_p
         L.nbody_abi_version.restype = C.c_int
         _lib = L
@@ -126,6 +127,16 @@ def comm_unique_id():
     buf = C.create_string_buffer(128)
     _check(lib().nbody_comm_unique_id(buf))
     return buf.raw
+
+
+def sort_pairs_u64(keys, vals, repeats=1):
+    """nbody_sort_pairs_u64 (parity hook): the Barnes-Hut build's own device sort of (uint64 key, int32 value) pairs,
+    stable; `repeats` sorts in a row on one state.  Returns (sorted keys, values)."""
+    k = np.ascontiguousarray(keys, np.uint64)
+    v = np.ascontiguousarray(vals, np.int32)
+    ok = np.empty_like(k); ov = np.empty_like(v)
+    _check(lib().nbody_sort_pairs_u64(k.ctypes.data, v.ctypes.data, len(k), ok.ctypes.data, ov.ctypes.data, int(repeats)))
+    return ok, ov
 
 
 def accel_noalloc(num_bodies, dev_m, dev_posX, dev_posY, dev_radius, dev_accX, dev_accY, hip_stream=None):

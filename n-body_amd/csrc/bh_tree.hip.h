@@ -48,6 +48,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "exact_core.hip.h"
+#include "bh_sort.hip.h"
 
 namespace nbody {
 
@@ -479,6 +480,44 @@ __global__ __launch_bounds__(kBhFixBlock) void bh_tie_fixpoint_kernel(const uint
     bh_tie_fixpoint_body(keys, vals, px, py, tie, ctr, T, ctr->valid);
 }
 
+// Large builds with a tie buffer of at most kBhSmallGhosts entries (up to 2^20 bodies): the fixed point AND the sort of the
+// second instances in one launch of one workgroup — bitonic in LDS over the G real instances, total order (key, body),
+// the rest of the buffer padded — instead of a device-wide sort of 4096 mostly-padding entries.
+constexpr int kBhSmallGhosts = 4096;                // second instances the LDS sort holds (= the tie buffer below 2^20 bodies)
+__global__ __launch_bounds__(kBhFixBlock) void bh_tie_fixpoint_sort_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
+                                                                           const float* __restrict__ px, const float* __restrict__ py,
+                                                                           const uint16_t* __restrict__ tie, BhCounters* __restrict__ ctr,
+                                                                           BhTies T, uint64_t* __restrict__ gkeys_sorted,
+                                                                           int* __restrict__ gvals_sorted)
+{
+    __shared__ uint64_t sk[kBhSmallGhosts];
+    __shared__ int sv[kBhSmallGhosts];
+    const int tid = threadIdx.x;
+    bh_tie_fixpoint_body(keys, vals, px, py, tie, ctr, T, ctr->valid);
+    __syncthreads();            // one workgroup = one CU = one L1: a barrier is all the ordering the phases need
+    const int ghosts = __hip_atomic_load(&ctr->ghosts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int gmax = T.gcap < kBhSmallGhosts ? T.gcap : kBhSmallGhosts;
+    const int G = ghosts < gmax ? ghosts : gmax;
+    if (G > 0) {
+        int P = 2;
+        while (P < G) P <<= 1;
+        for (int e = tid; e < P; e += kBhFixBlock) { sk[e] = e < G ? T.gkeys[e] : ~0ull; sv[e] = e < G ? T.gvals[e] : -1; }
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int p = tid; p < (P >> 1); p += kBhFixBlock) {
+                    const int lo = ((p & ~(j - 1)) << 1) | (p & (j - 1)), hi = lo | j;
+                    const uint64_t ka = sk[lo], kb = sk[hi];
+                    const int va = sv[lo], vb = sv[hi];
+                    const bool gt = ka > kb || (ka == kb && va > vb);          // total order (key, body)
+                    if (gt == ((lo & k) == 0)) { sk[lo] = kb; sk[hi] = ka; sv[lo] = vb; sv[hi] = va; }
+                }
+                __syncthreads();
+            }
+    }
+    for (int e = tid; e < T.gcap; e += kBhFixBlock) { gkeys_sorted[e] = e < G ? sk[e] : ~0ull; gvals_sorted[e] = e < G ? sv[e] : -1; }
+}
+
 // merge sorted primaries [n] and sorted second instances [gcap] into one sorted array [n + gcap]
 __device__ __forceinline__ void bh_merge_one(int t, const uint64_t* __restrict__ keys, const int* __restrict__ vals, int n,
                                              const uint64_t* __restrict__ gkeys, const int* __restrict__ gvals, int gcap,
@@ -572,13 +611,119 @@ __global__ __launch_bounds__(kBhBlock) void bh_owner_kernel(const int* __restric
         if (c0 + k < cap_internal) owner[c0 + k] = i;
 }
 
+// 3 + 4a in ONE launch (large builds; was bh_count_kernel + a library scan + bh_owner_kernel): cells owned by each sorted
+// instance, their exclusive scan = cell ids, and the owner scatter.  A workgroup takes the next tile of 256 x R
+// instances by ticket; each wave walks R rounds of 64 consecutive instances (neighbours' keys by shuffle, as
+// bh_prep_small_kernel does), the tile total is published and the totals of all tiles before it are collected by
+// decoupled look-back — one 64-bit word per tile {epoch, flag, count}, device-scope relaxed atomics, 64 predecessor
+// tiles examined per step by wave 0.  Waits are bounded as in bh_sort.hip.h.  The last workgroup to finish resets the
+// ticket and opens the next epoch.
+struct ScanState { unsigned epoch; int ticket; int done; int error; };
+constexpr int kBhScanRounds = 8;
+
+__global__ __launch_bounds__(kBhBlock) void bh_cells_scan_kernel(const uint64_t* __restrict__ keys, int nm,
+                                                                 const BhCounters* __restrict__ ctr, ScanState* __restrict__ ss,
+                                                                 unsigned long long* __restrict__ look, int* __restrict__ cnt,
+                                                                 int* __restrict__ base, int* __restrict__ owner, int cap_internal)
+{
+    constexpr int R = kBhScanRounds, T = kBhBlock * R;
+    __shared__ int s_tile;
+    __shared__ int wave_total[kBhBlock / 64];
+    __shared__ int s_excl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned epoch = ss->epoch;
+    const int M = ctr->valid;
+    if (tid == 0) s_tile = atomicAdd(&ss->ticket, 1);
+    __syncthreads();
+    const int tile = s_tile;
+    if ((long long)tile * T < nm) {
+        const int w0 = tile * T + wave * (64 * R);
+        uint64_t kc[R], ke[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = w0 + r * 64 + lane;
+            kc[r] = i < M ? keys[i] : 0;
+            const int j = lane == 0 ? w0 + r * 64 - 1 : w0 + r * 64 + 64;      // lane 0: the key before the round, lane 63: after
+            ke[r] = (lane == 0 || lane == 63) && j >= 0 && j < M ? keys[j] : 0;
+        }
+        int c[R], incl[R], running = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = w0 + r * 64 + lane;
+            uint64_t kp = __shfl_up(kc[r], 1, 64), kn = __shfl_down(kc[r], 1, 64);
+            if (lane == 0) kp = ke[r];
+            if (lane == 63) kn = ke[r];
+            const int lp = i > 0 && i < M ? bh_lcp_levels(kp, kc[r]) : -1;
+            const int ln = i + 1 < M ? bh_lcp_levels(kc[r], kn) : -1;
+            c[r] = i < M && ln > lp ? ln - lp : 0;                             // = bh_count_one(i, M, keys)
+            int v = c[r];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(v, off, 64);
+                if (lane >= off) v += t;
+            }
+            incl[r] = running + v;
+            running += __shfl(v, 63, 64);
+        }
+        if (lane == 0) wave_total[wave] = running;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kBhBlock / 64; ++w) { const int p = wave_total[w]; if (w < wave) before += p; total += p; }
+        if (wave == 0) {
+            const unsigned long long tagw = (unsigned long long)epoch << 32;
+            if (lane == 0) sort_look_store(look + tile, tagw | (tile == 0 ? kLookPrefix : kLookAgg) | (unsigned)total);
+            int excl = 0, at = tile - 1, spins = 0;
+            while (at >= 0) {
+                const int j = at - lane;
+                const unsigned long long w = j >= 0 ? sort_look_load(look + j) : (tagw | kLookPrefix);   // before tile 0: nothing
+                const bool ready = (unsigned)(w >> 32) == epoch && (w & (kLookAgg | kLookPrefix));
+                const unsigned long long not_ready = __ballot(!ready), prefix = __ballot(ready && (w & kLookPrefix));
+                const int first_nr = not_ready ? __builtin_ctzll(not_ready) : 64, first_pf = prefix ? __builtin_ctzll(prefix) : 64;
+                const int take = first_pf < first_nr ? first_pf + 1 : first_nr;       // lanes [0, take) are summed
+                int v = lane < take ? (int)(w & kLookCount) : 0;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                excl += v;
+                if (first_pf < first_nr) break;
+                at -= take;
+                if (take == 0) {
+                    if (++spins > kSortSpinLimit) { if (lane == 0) ss->error = 1; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            if (lane == 0) {
+                if (tile > 0) sort_look_store(look + tile, tagw | kLookPrefix | (unsigned)(excl + total));
+                s_excl = excl;
+            }
+        }
+        __syncthreads();
+        const int offset = s_excl + before;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = w0 + r * 64 + lane;
+            if (i < nm) {
+                const int first = offset + incl[r] - c[r];
+                cnt[i] = c[r];
+                base[i] = first;
+                for (int q = 0; q < c[r]; ++q)
+                    if (first + q < cap_internal) owner[first + q] = i;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int before = atomicAdd(&ss->done, 1);
+        if (before == (int)gridDim.x - 1) { ss->done = 0; ss->ticket = 0; ss->epoch = epoch + 1; }
+    }
+}
+
 // Small N: steps 2b-4a in ONE launch of one workgroup (valid count, split-line instances and their fixed point, their
 // sort — bitonic in LDS, nothing to do when there are none —, merge, cell counting, exclusive scan, owner scatter).
 // At N = 10 000 these were 12 launches of 4-5 us each around a few hundred nanoseconds of work (the reference's own
 // default size, benchmark.cpp:302; a captured graph replays launches no faster than the stream issues them).
 // Same device functions as the separate kernels, phases separated by workgroup barriers; results are identical.
 constexpr int kBhSmallMax = 32768;                  // bodies; above, the phases are separate full-width launches
-constexpr int kBhSmallGhosts = 4096;                // second instances the LDS sort holds (= the tie buffer below 2^20 bodies)
 
 __global__ __launch_bounds__(kBhFixBlock) void bh_prep_small_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
                                                                     const float* __restrict__ px, const float* __restrict__ py,
@@ -740,6 +885,8 @@ __global__ __launch_bounds__(kBhFixBlock) void bh_prep_small_kernel(const uint64
     BH_DBG_TICK(ctr, 6);
 }
 
+struct BhWaitErrors { const int* p[3]; };      // SortState::error / ScanState::error of the kernels before (nullptr: not used)
+
 // 4b. one thread per internal cell: box, body range (galloping from the owner: the range of a typical cell is a
 // few bodies long), the four children.
 __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys, const int* vals,
@@ -750,7 +897,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
                                                             BhCounters* __restrict__ ctr, int* __restrict__ overflow_host,
                                                             const uint64_t* __restrict__ keys_unmerged,
                                                             const int* __restrict__ vals_unmerged,
-                                                            const float4* __restrict__ body4)
+                                                            const float4* __restrict__ body4, BhWaitErrors werr)
 {
     // small-N build: without second instances the merged arrays were never written, they ARE the sorted primaries
     if (keys_unmerged != nullptr && ctr->ghosts == 0) { keys = keys_unmerged; vals = vals_unmerged; }
@@ -763,7 +910,10 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
         if (I > t.cap_internal) ctr->overflow = 1;
         // the build's verdict goes to a host-mapped word, so that nbody_sync needs no device-to-host copy (the tie
         // buffer's overflow, 2, was set by the kernels before this one)
-        overflow_host[0] = I > t.cap_internal ? 1 : ctr->overflow;
+        int verdict = I > t.cap_internal ? 1 : ctr->overflow;
+        for (int k = 0; k < 3; ++k)
+            if (werr.p[k] && *werr.p[k]) verdict = 3;          // a bounded look-back wait of the sort / scan gave up
+        overflow_host[0] = verdict;
         for (int k = 0; k < 64; ++k) ctr->valid_part[k] = 0;            // everybody has read ctr->valid by now
         if (M < 2) {                                           // degenerate trees: root is a leaf / empty
             const int b = M == 1 ? vals[0] : -1;

@@ -138,11 +138,16 @@ struct nbody_ctx {
         unsigned char* tie_first_sorted = nullptr;   //   first split-line level of each body, in sorted order [n]
         void *sort_tmp = nullptr, *scan_tmp = nullptr;
         size_t sort_bytes = 0, scan_bytes = 0;
+        // this repository's sort and scan (bh_sort.hip.h); the rocPRIM ones above stay as the alternative path (NBODY_BH_HIPCUB)
+        SortBuffers sort_main, sort_ghost, sort_own;
+        ScanState* scan_state = nullptr;
+        unsigned long long* scan_look = nullptr;
         int64_t node_cap = 0;
     } bh;
 };
 
 void destroy_comm(nbody_ctx* ctx);   // comm_rccl.hip.h
+namespace { void drop_step_graph(nbody_ctx* ctx); }
 
 namespace {
 
@@ -270,6 +275,7 @@ int enqueue_bh_build(nbody_ctx* ctx)
     const bool fused = n <= kBhSmallMax && b.gcap <= kBhSmallGhosts && !std::getenv("NBODY_BH_NO_FUSE");
     bh_keys_kernel<<<grid_n, blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr, ctx->cfg.spread, adaptive ? 0 : 1, b.keys, b.vals, b.tie,
                                           b.gkeys, b.gvals, b.gcap, b.tie_table, b.tie_table_size, fused ? 1 : 0, ctx->m, b.body4);
+    const bool use_hipcub = std::getenv("NBODY_BH_HIPCUB") != nullptr;    // developer/test switch: rocPRIM's sort and scan
     const char* rank_env = std::getenv("NBODY_BH_RANKSORT_MAX");         // developer/test switch
     // (the rank buffers exist only up to kBhRankSortMax bodies, nbody_create: the knob can lower the limit, never raise it)
     const int rank_max = rank_env ? (std::atoi(rank_env) < kBhRankSortMax ? std::atoi(rank_env) : kBhRankSortMax) : kBhRankSortMax;
@@ -282,9 +288,11 @@ int enqueue_bh_build(nbody_ctx* ctx)
         slices = (n + per - 1) / per;
         bh_ranksort_kernel<<<dim3(grid_n.x, slices), blk, 0, s>>>(b.keys, b.vals, n, per, b.rank, b.rank_done, b.keys_sorted, b.vals_sorted,
                                                                   b.tie, b.tie_first_sorted);
-    } else {
+    } else if (use_hipcub) {
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, b.keys, b.keys_sorted, b.vals, b.vals_sorted, n,
                                                    0, 64, s));
+    } else {
+        sort_pairs(b.sort_main, b.keys, b.vals, b.keys_sorted, b.vals_sorted, n, s);      // TMP = the merged arrays, written later
     }
     // bodies exactly on a split line get a second instance (inclusive bounds, benchmark.cpp:83-85)
     BhTies ties{b.gkeys, b.gvals, b.gfx, b.gfy, b.gld, b.glo, b.ghi, b.gpos, b.pld, b.tie_table, b.tie_table_size - 1, b.gcap};
@@ -296,19 +304,37 @@ int enqueue_bh_build(nbody_ctx* ctx)
     } else {
         bh_valid_kernel<<<1, 64, 0, s>>>(b.keys_sorted, n, b.ctr);
         bh_ties_kernel<<<grid_n, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties);
-        bh_tie_fixpoint_kernel<<<1, kBhFixBlock, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties);
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.gsort_tmp, b.gsort_bytes, b.gkeys, b.gkeys_sorted, b.gvals, b.gvals_sorted,
-                                                   b.gcap, 0, 64, s));
+        if (use_hipcub) {
+            bh_tie_fixpoint_kernel<<<1, kBhFixBlock, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties);
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.gsort_tmp, b.gsort_bytes, b.gkeys, b.gkeys_sorted, b.gvals, b.gvals_sorted,
+                                                       b.gcap, 0, 64, s));
+        } else if (b.gcap <= kBhSmallGhosts) {
+            // up to 2^20 bodies: the fixed point and the (LDS) sort of the few second instances in one launch
+            bh_tie_fixpoint_sort_kernel<<<1, kBhFixBlock, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties,
+                                                                  b.gkeys_sorted, b.gvals_sorted);
+        } else {
+            bh_tie_fixpoint_kernel<<<1, kBhFixBlock, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties);
+            sort_pairs(b.sort_ghost, b.gkeys, b.gvals, b.gkeys_sorted, b.gvals_sorted, b.gcap, s);    // padding (~0) sorts last
+        }
         bh_merge_kernel<<<grid_m, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, n, b.gkeys_sorted, b.gvals_sorted, b.gcap,
                                                b.keys_merged, b.vals_merged, b.ctr);
-        bh_count_kernel<<<grid_m, blk, 0, s>>>(b.keys_merged, nm, b.ctr, b.cnt);
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b.scan_tmp, b.scan_bytes, b.cnt, b.base, nm, s));
-        bh_owner_kernel<<<grid_m, blk, 0, s>>>(b.cnt, b.base, nm, b.ctr, b.owner, b.tree.cap_internal);
+        if (use_hipcub) {
+            bh_count_kernel<<<grid_m, blk, 0, s>>>(b.keys_merged, nm, b.ctr, b.cnt);
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b.scan_tmp, b.scan_bytes, b.cnt, b.base, nm, s));
+            bh_owner_kernel<<<grid_m, blk, 0, s>>>(b.cnt, b.base, nm, b.ctr, b.owner, b.tree.cap_internal);
+        } else {
+            constexpr int kScanTile = kBhBlock * kBhScanRounds;
+            bh_cells_scan_kernel<<<dim3((nm + kScanTile - 1) / kScanTile), blk, 0, s>>>(b.keys_merged, nm, b.ctr, b.scan_state, b.scan_look,
+                                                                                       b.cnt, b.base, b.owner, b.tree.cap_internal);
+        }
     }
+    BhWaitErrors werr{{nullptr, nullptr, nullptr}};
+    if (!use_hipcub && !ranked) werr.p[0] = &b.sort_main.state->error;
+    if (!use_hipcub && !fused) { werr.p[1] = &b.scan_state->error; if (b.gcap > kBhSmallGhosts) werr.p[2] = &b.sort_ghost.state->error; }
     const dim3 grid_c((b.tree.cap_internal + kBhBlock - 1) / kBhBlock);
     bh_nodes_kernel<<<grid_c, blk, 0, s>>>(b.keys_merged, b.vals_merged, b.cnt, b.base, b.owner, nm, ctx->m, ctx->px, ctx->py,
                                            b.tree, b.ctr, b.overflow_dev, fused ? b.keys_sorted : nullptr,
-                                           fused ? b.vals_sorted : nullptr, b.body4);
+                                           fused ? b.vals_sorted : nullptr, b.body4, werr);
     // centre of mass: one launch in which the last child to finish evaluates its parent; for very large trees one
     // launch per depth (31 launches of >= 4.5 us, but their loads hit the L2: faster above ~2 x 10^6 bodies)
     const char* climb_env = std::getenv("NBODY_BH_CLIMB_MAX");          // developer/test switch, read per enqueue
@@ -340,8 +366,11 @@ int enqueue_bh_walk(nbody_ctx* ctx, int advance)
         auto& b = ctx->bh;
         if (b.own_order) {
             const int sb = ctx->cfg.shard_begin, sc = ctx->i_end - ctx->i_begin;
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.own_sort_tmp, b.own_sort_bytes, b.keys + sb, b.own_keys_sorted, b.vals + sb,
-                                                       b.own_order, sc, 0, 64, ctx->stream));
+            if (std::getenv("NBODY_BH_HIPCUB"))
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.own_sort_tmp, b.own_sort_bytes, b.keys + sb, b.own_keys_sorted, b.vals + sb,
+                                                           b.own_order, sc, 0, 64, ctx->stream));
+            else
+                sort_pairs(b.sort_own, b.keys + sb, b.vals + sb, b.own_keys_sorted, b.own_order, sc, ctx->stream);
             w.order = b.own_order - sb;
         } else {
             w.order = b.vals_sorted;
@@ -403,8 +432,9 @@ ForcePlan make_force_plan(int n, int nt, int variant, int max_slices, int k_req 
     if (p.blocks_x < 1) p.blocks_x = 1;
     int want = slices_req ? slices_req : (8192 + p.blocks_x - 1) / p.blocks_x;   // aim for >= 8192 workgroups (measured: tools/sweep.py)
     if (want > max_slices) want = max_slices;
-    // tile: the big one unless that leaves fewer slices than wanted
-    p.tile = tile_req ? tile_req : (((n + want - 1) / want >= big) ? big : kTileSmall);
+    // tile: the big one unless that leaves fewer than HALF the slices wanted (N = 65 536: 32 slices of one 2048-source
+    // tile run 0.8 % faster than 64 slices of four 256-source tiles and halve the partial rows, profiles/r3_force_plan_sweep.txt)
+    p.tile = tile_req ? tile_req : (((n + want - 1) / want >= big / 2) ? big : kTileSmall);
     const int max_slices_by_n = (n + p.tile - 1) / p.tile;
     if (want > max_slices_by_n) want = max_slices_by_n;
     if (want < 1) want = 1;
@@ -597,9 +627,35 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
         HIP_TRY_C(hipcub::DeviceRadixSort::SortPairs(nullptr, b.sort_bytes, b.keys, b.keys_sorted, b.vals, b.vals_sorted, n, 0, 64, ctx->stream));
         HIP_TRY_C(hipcub::DeviceRadixSort::SortPairs(nullptr, b.gsort_bytes, b.gkeys, b.gkeys_sorted, b.gvals, b.gvals_sorted, b.gcap, 0, 64, ctx->stream));
         HIP_TRY_C(hipcub::DeviceScan::ExclusiveSum(nullptr, b.scan_bytes, b.cnt, b.base, (int)nm, ctx->stream));
+        // own sort / scan state: zeroed once, epochs start at 1 (no tag then equals a zero-initialised look-back word's)
+        auto make_sort = [&](SortBuffers& sbuf, int count, uint64_t* tmp_k, int* tmp_v) -> hipError_t {
+            hipError_t e = hipMalloc((void**)&sbuf.state, sizeof(SortState));
+            if (e != hipSuccess) return e;
+            if ((e = hipMemset(sbuf.state, 0, sizeof(SortState))) != hipSuccess) return e;
+            const unsigned one = 1;
+            if ((e = hipMemcpy(&sbuf.state->epoch, &one, sizeof(one), hipMemcpyHostToDevice)) != hipSuccess) return e;
+            sbuf.tiles = sort_tiles(count);
+            const size_t lb = sizeof(unsigned long long) * (size_t)sbuf.tiles * kSortBins;
+            if ((e = hipMalloc((void**)&sbuf.look, lb)) != hipSuccess) return e;
+            if ((e = hipMemset(sbuf.look, 0, lb)) != hipSuccess) return e;
+            if (tmp_k) { sbuf.tmp_k = tmp_k; sbuf.tmp_v = tmp_v; return hipSuccess; }
+            if ((e = hipMalloc((void**)&sbuf.tmp_k, sizeof(uint64_t) * (size_t)count)) != hipSuccess) return e;
+            return hipMalloc((void**)&sbuf.tmp_v, sizeof(int) * (size_t)count);
+        };
+        HIP_TRY_C(make_sort(b.sort_main, n, b.keys_merged, b.vals_merged));      // the merged arrays are written after the sort
+        if (b.gcap > kBhSmallGhosts) HIP_TRY_C(make_sort(b.sort_ghost, b.gcap, nullptr, nullptr));
+        {
+            HIP_TRY_C(hipMalloc((void**)&b.scan_state, sizeof(ScanState)));
+            const ScanState s0{1u, 0, 0, 0};
+            HIP_TRY_C(hipMemcpy(b.scan_state, &s0, sizeof(s0), hipMemcpyHostToDevice));
+            const size_t tiles = (nm + (size_t)kBhBlock * kBhScanRounds - 1) / ((size_t)kBhBlock * kBhScanRounds);
+            HIP_TRY_C(hipMalloc((void**)&b.scan_look, sizeof(unsigned long long) * tiles));
+            HIP_TRY_C(hipMemset(b.scan_look, 0, sizeof(unsigned long long) * tiles));
+        }
         if (cfg->bh_sorted && sc < n && sc > 0) {
             HIP_TRY_C(hipMalloc((void**)&b.own_keys_sorted, sizeof(uint64_t) * (size_t)sc));
             HIP_TRY_C(hipMalloc((void**)&b.own_order, sizeof(int) * (size_t)sc));
+            HIP_TRY_C(make_sort(b.sort_own, sc, nullptr, nullptr));
             HIP_TRY_C(hipcub::DeviceRadixSort::SortPairs(nullptr, b.own_sort_bytes, b.keys, b.own_keys_sorted, b.vals, b.own_order, sc, 0, 64, ctx->stream));
             HIP_TRY_C(hipMalloc(&b.own_sort_tmp, b.own_sort_bytes ? b.own_sort_bytes : 16));
         }
@@ -628,7 +684,9 @@ void nbody_destroy(nbody_ctx* ctx)
         void* ptrs[] = {b.keys, b.keys_sorted, b.vals, b.vals_sorted, b.cnt, b.base, b.tree.A, b.tree.B,
                         b.tree.depth, b.tree.self, b.tree.pend, b.rank, b.rank_done, b.tie_first_sorted, b.body4, b.ctr, b.tie, b.owner, b.gfx, b.gfy, b.gld, b.pld, b.glo, b.ghi, b.gpos, b.tie_table, b.sort_tmp, b.scan_tmp, b.gkeys, b.gkeys_sorted, b.gvals,
                         b.gvals_sorted, b.keys_merged, b.vals_merged, b.gsort_tmp, b.grp_visits, b.grp_accepts,
-                        b.own_keys_sorted, b.own_order, b.own_sort_tmp};
+                        b.own_keys_sorted, b.own_order, b.own_sort_tmp,
+                        b.sort_main.state, b.sort_main.look, b.sort_ghost.state, b.sort_ghost.look, b.sort_ghost.tmp_k, b.sort_ghost.tmp_v,
+                        b.sort_own.state, b.sort_own.look, b.sort_own.tmp_k, b.sort_own.tmp_v, b.scan_state, b.scan_look};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (b.overflow_host) (void)hipHostFree(b.overflow_host);
@@ -698,12 +756,9 @@ int nbody_upload(nbody_ctx* ctx, const float* m, const float* posX, const float*
     ctx->out_scale = variant == kScaled ? m[0] / (r0 * r0) : (variant == kUniform ? m[0] : 1.0f);
     plan_force(ctx);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    drop_step_graph(ctx);                        // variant, launch plan and buffers may all change: re-capture on the next step
     const int rows = ctx->cfg.use_barnes_hut ? 1 : ctx->slices;
     if (rows > ctx->partial_rows) {
-        if (ctx->step_graph) {                   // the partial buffers move: re-capture on the next step
-            (void)hipGraphExecDestroy(ctx->step_graph);
-            ctx->step_graph = nullptr;
-        }
         if (ctx->pax) HIP_TRY(hipFree(ctx->pax));
         if (ctx->pay) HIP_TRY(hipFree(ctx->pay));
         ctx->pax = ctx->pay = nullptr;
@@ -776,11 +831,12 @@ void drop_step_graph(nbody_ctx* ctx)
     ctx->step_graph_stream = nullptr;
 }
 
-// Capture one step into a hipGraph (Barnes-Hut only; skipped while per-kernel event timing is on, because
+// Capture one step into a hipGraph (both step kinds: the Barnes-Hut step is 6-50 launches, the naive step two — at
+// the reference's default N = 10 000 those two are launch-bound; skipped while per-kernel event timing is on, because
 // event pairs recorded inside a capture cannot be queried).  Any failure falls back to eager launches for good.
 bool ensure_step_graph(nbody_ctx* ctx)
 {
-    if (!ctx->cfg.use_barnes_hut || ctx->prof.on || ctx->graph_failed || std::getenv("NBODY_NO_GRAPH")) return false;
+    if (ctx->prof.on || ctx->graph_failed || std::getenv("NBODY_NO_GRAPH")) return false;
     if (ctx->step_graph && ctx->step_graph_stream == ctx->stream) return true;
     drop_step_graph(ctx);
     hipGraph_t graph = nullptr;
@@ -894,6 +950,9 @@ int nbody_sync(nbody_ctx* ctx)
         if (overflow == 1)
             return fail(NBODY_ERR_INVALID, "Barnes-Hut node pool exhausted (%d internal cells); bodies were dropped from the tree "
                                            "as the reference does at benchmark.cpp:102", ctx->bh.tree.cap_internal);
+        if (overflow == 3)
+            return fail(NBODY_ERR_HIP, "Barnes-Hut build: a bounded look-back wait of the device sort/scan gave up (internal error; "
+                                       "the tree of this step is not valid)");
         if (overflow == 2)
             return fail(NBODY_ERR_INVALID, "Barnes-Hut: more than %d bodies sit exactly on split lines; the surplus was inserted once",
                         ctx->bh.gcap);
@@ -1223,6 +1282,58 @@ int nbody_accel_noalloc(int32_t num_bodies, const float* dev_m, const float* dev
     }
     HIP_TRY(hipGetLastError());
     return NBODY_OK;
+}
+
+// Parity hook for bh_sort.hip.h: the build's own device sort on host arrays (tests compare with a stable host sort).
+int nbody_sort_pairs_u64(const uint64_t* keys, const int32_t* vals, int32_t n, uint64_t* out_keys, int32_t* out_vals, int32_t repeats)
+{
+    if (!keys || !vals || !out_keys || !out_vals || n < 1 || repeats < 1) return fail(NBODY_ERR_INVALID, "nbody_sort_pairs_u64: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(NBODY_ERR_NO_DEVICE, "nbody_sort_pairs_u64: no HIP device visible");
+    SortBuffers sb;
+    uint64_t *dk = nullptr, *ok = nullptr;
+    int *dv = nullptr, *ov = nullptr;
+    SortState host_state{};
+    auto run = [&]() -> int {
+        const size_t kb = sizeof(uint64_t) * (size_t)n, vb = sizeof(int) * (size_t)n;
+        HIP_TRY(hipMalloc((void**)&dk, kb)); HIP_TRY(hipMalloc((void**)&ok, kb));
+        HIP_TRY(hipMalloc((void**)&dv, vb)); HIP_TRY(hipMalloc((void**)&ov, vb));
+        HIP_TRY(hipMalloc((void**)&sb.tmp_k, kb)); HIP_TRY(hipMalloc((void**)&sb.tmp_v, vb));
+        HIP_TRY(hipMalloc((void**)&sb.state, sizeof(SortState)));
+        HIP_TRY(hipMemset(sb.state, 0, sizeof(SortState)));
+        const unsigned one = 1;
+        HIP_TRY(hipMemcpy(&sb.state->epoch, &one, sizeof(one), hipMemcpyHostToDevice));
+        const size_t lb = sizeof(unsigned long long) * (size_t)sort_tiles(n) * kSortBins;
+        HIP_TRY(hipMalloc((void**)&sb.look, lb));
+        HIP_TRY(hipMemset(sb.look, 0, lb));
+        HIP_TRY(hipMemcpy(dk, keys, kb, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dv, vals, vb, hipMemcpyHostToDevice));
+        for (int r = 0; r < repeats; ++r) {                       // repeats: the state (epochs, tickets, histograms) carries over
+            HIP_TRY(hipMemsetAsync(ok, 0xA5, kb, nullptr));
+            sort_pairs(sb, dk, dv, ok, ov, n, nullptr);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out_keys, ok, kb, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_vals, ov, vb, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&host_state, sb.state, sizeof(SortState), hipMemcpyDeviceToHost));
+        return NBODY_OK;
+    };
+    int rc = run();
+    void* ptrs[] = {dk, ok, dv, ov, sb.tmp_k, sb.tmp_v, sb.state, sb.look};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+#ifdef NBODY_WIDE_TIMING
+    if (rc == NBODY_OK && host_state.dbg_cnt) {
+        const char* nm[] = {"plan+ticket", "loads", "rank", "bins+scans", "look-back", "LDS scatter", "global scatter"};
+        for (int q = 0; q < 7; ++q)
+            std::fprintf(stderr, "[sort] n=%d up to '%s': mean %.2f us  max %.2f us (per live tile, since the workgroup started)\n", n, nm[q],
+                         (double)host_state.dbg_sum[q] / (double)host_state.dbg_cnt * 0.01, (double)host_state.dbg_max[q] * 0.01);
+    }
+#endif
+    if (rc == NBODY_OK && host_state.error) rc = fail(NBODY_ERR_HIP, "nbody_sort_pairs_u64: a look-back wait gave up");
+    if (rc == NBODY_OK && host_state.epoch != 1u + (unsigned)repeats) rc = fail(NBODY_ERR_HIP, "nbody_sort_pairs_u64: epoch %u after %d sorts", host_state.epoch, repeats);
+    return rc;
 }
 
 const char* nbody_last_error(void) { return g_err; }

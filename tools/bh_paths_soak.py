@@ -15,7 +15,8 @@ from bh_stress import make
 
 ALT = {"NBODY_BH_NO_FUSE": "1", "NBODY_BH_RANKSORT_MAX": "0", "NBODY_BH_CLIMB_MAX": "0", "NBODY_BH_QUAD_MAX": "0",
        "NBODY_NO_GRAPH": "1",                 # eager launches instead of the captured step graph
-       "NBODY_BH_NO_CORE": "1"}               # hipcc's IEEE sqrt and divisions instead of exact_core.hip.h's sequences
+       "NBODY_BH_NO_CORE": "1",               # hipcc's IEEE sqrt and divisions instead of exact_core.hip.h's sequences
+       "NBODY_BH_HIPCUB": "1"}                # rocPRIM's radix sort and scan instead of csrc/bh_sort.hip.h
 
 
 def run(b, theta, env, steps, **kw):
