@@ -217,9 +217,11 @@ int nbody_accel_noalloc(int32_t num_bodies, const float *dev_m, const float *dev
 /* Parity hook for the Barnes-Hut build's own device sort (csrc/bh_sort.hip.h; it replaces the order the reference gets
    from serial insertion, benchmark.cpp:171-172): sorts n (key, value) pairs by key, STABLY, on the current device —
    host arrays in and out, `repeats` sorts in a row on the same state (epochs, tickets and histograms carry over as
-   they do from build to build).  Not on any step path. */
+   they do from build to build).  truncated != 0: the form the build uses — five sweeps over bits 24-63, then the runs
+   of equal prefixes are finished by the two run kernels; the result is the same full 64-bit stable order.  Not on any
+   step path. */
 int nbody_sort_pairs_u64(const uint64_t *keys, const int32_t *vals, int32_t n, uint64_t *out_keys, int32_t *out_vals,
-                         int32_t repeats);
+                         int32_t repeats, int32_t truncated);
 
 const char *nbody_last_error(void); /* thread-local, never NULL */
 int nbody_abi_version(void);

@@ -90,7 +90,7 @@ def lib():
         L.nbody_bh_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.nbody_bh_group_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.nbody_accel_noalloc.argtypes = [C.c_int32] + [C.c_void_p] * 7
-        L.nbody_sort_pairs_u64.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+        L.nbody_sort_pairs_u64.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.nbody_last_error.restype = C.c_char_p
         L.nbody_abi_version.restype = C.c_int
         _lib = L
@@ -129,13 +129,13 @@ def comm_unique_id():
     return buf.raw
 
 
-def sort_pairs_u64(keys, vals, repeats=1):
+def sort_pairs_u64(keys, vals, repeats=1, truncated=False):
     """nbody_sort_pairs_u64 (parity hook): the Barnes-Hut build's own device sort of (uint64 key, int32 value) pairs,
     stable; `repeats` sorts in a row on one state.  Returns (sorted keys, values)."""
     k = np.ascontiguousarray(keys, np.uint64)
     v = np.ascontiguousarray(vals, np.int32)
     ok = np.empty_like(k); ov = np.empty_like(v)
-    _check(lib().nbody_sort_pairs_u64(k.ctypes.data, v.ctypes.data, len(k), ok.ctypes.data, ov.ctypes.data, int(repeats)))
+    _check(lib().nbody_sort_pairs_u64(k.ctypes.data, v.ctypes.data, len(k), ok.ctypes.data, ov.ctypes.data, int(repeats), int(bool(truncated))))
     return ok, ov
 
 

@@ -126,7 +126,9 @@ __global__ __launch_bounds__(kBhBlock) void bh_keys_kernel(const float* __restri
         uint64_t key;
         int tx = kBhLevels, ty = kBhLevels;                    // first level at which x (y) sits ON the split line
         if (x < tlx || x > brx || y < tly || y > bry) {         // benchmark.cpp:83-85
-            key = kBhInvalidKey | (uint64_t)(uint32_t)i;       // keep invalid keys distinct and ordered
+            // invalid keys stay distinct and ordered by body; the index sits ABOVE bit 24 (it fits: n < 2^28), so that
+            // the sort's truncated sweeps (bits 24-63, bh_sort.hip.h) already order them completely
+            key = kBhInvalidKey | ((uint64_t)(uint32_t)i << 24);
         } else {
             inside = true;
             key = 0;
@@ -516,6 +518,30 @@ __global__ __launch_bounds__(kBhFixBlock) void bh_tie_fixpoint_sort_kernel(const
             }
     }
     for (int e = tid; e < T.gcap; e += kBhFixBlock) { gkeys_sorted[e] = e < G ? sk[e] : ~0ull; gvals_sorted[e] = e < G ? sv[e] : -1; }
+    if (ghosts <= kBhSmallGhosts || T.gcap <= kBhSmallGhosts) return;
+    // More second instances than the LDS holds (only with more than 2^20 bodies, and then only on inputs with thousands
+    // of bodies exactly on split lines): the same bitonic network over the output arrays in device memory, still one
+    // workgroup.  Slow (milliseconds) and rare; the arrays are allocated to the next power of two.  Loads bypass the L1.
+    const int GG = ghosts < T.gcap ? ghosts : T.gcap;
+    int P = 2;
+    while (P < GG) P <<= 1;
+    __syncthreads();
+    for (int e = tid; e < P; e += kBhFixBlock) { gkeys_sorted[e] = e < GG ? T.gkeys[e] : ~0ull; gvals_sorted[e] = e < GG ? T.gvals[e] : -1; }
+    __syncthreads();
+    unsigned long long* gk = reinterpret_cast<unsigned long long*>(gkeys_sorted);
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = tid; p < (P >> 1); p += kBhFixBlock) {
+                const int lo = ((p & ~(j - 1)) << 1) | (p & (j - 1)), hi = lo | j;
+                const uint64_t ka = __hip_atomic_load(gk + lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint64_t kb = __hip_atomic_load(gk + hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int va = __hip_atomic_load(gvals_sorted + lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int vb = __hip_atomic_load(gvals_sorted + hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool gt = ka > kb || (ka == kb && va > vb);
+                if (gt == ((lo & k) == 0)) { gkeys_sorted[lo] = kb; gkeys_sorted[hi] = ka; gvals_sorted[lo] = vb; gvals_sorted[hi] = va; }
+            }
+            __syncthreads();
+        }
 }
 
 // merge sorted primaries [n] and sorted second instances [gcap] into one sorted array [n + gcap]

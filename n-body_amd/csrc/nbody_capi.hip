@@ -139,7 +139,7 @@ struct nbody_ctx {
         void *sort_tmp = nullptr, *scan_tmp = nullptr;
         size_t sort_bytes = 0, scan_bytes = 0;
         // this repository's sort and scan (bh_sort.hip.h); the rocPRIM ones above stay as the alternative path (NBODY_BH_HIPCUB)
-        SortBuffers sort_main, sort_ghost, sort_own;
+        SortBuffers sort_main, sort_own;
         ScanState* scan_state = nullptr;
         unsigned long long* scan_look = nullptr;
         int64_t node_cap = 0;
@@ -292,7 +292,7 @@ int enqueue_bh_build(nbody_ctx* ctx)
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, b.keys, b.keys_sorted, b.vals, b.vals_sorted, n,
                                                    0, 64, s));
     } else {
-        sort_pairs(b.sort_main, b.keys, b.vals, b.keys_sorted, b.vals_sorted, n, s);      // TMP = the merged arrays, written later
+        sort_pairs(b.sort_main, b.keys, b.vals, b.keys_sorted, b.vals_sorted, n, s, true);    // TMP = the merged arrays, written later
     }
     // bodies exactly on a split line get a second instance (inclusive bounds, benchmark.cpp:83-85)
     BhTies ties{b.gkeys, b.gvals, b.gfx, b.gfy, b.gld, b.glo, b.ghi, b.gpos, b.pld, b.tie_table, b.tie_table_size - 1, b.gcap};
@@ -308,13 +308,10 @@ int enqueue_bh_build(nbody_ctx* ctx)
             bh_tie_fixpoint_kernel<<<1, kBhFixBlock, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties);
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.gsort_tmp, b.gsort_bytes, b.gkeys, b.gkeys_sorted, b.gvals, b.gvals_sorted,
                                                        b.gcap, 0, 64, s));
-        } else if (b.gcap <= kBhSmallGhosts) {
-            // up to 2^20 bodies: the fixed point and the (LDS) sort of the few second instances in one launch
+        } else {
+            // the fixed point and the sort of the few second instances in one launch (in LDS up to 4096 of them)
             bh_tie_fixpoint_sort_kernel<<<1, kBhFixBlock, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties,
                                                                   b.gkeys_sorted, b.gvals_sorted);
-        } else {
-            bh_tie_fixpoint_kernel<<<1, kBhFixBlock, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties);
-            sort_pairs(b.sort_ghost, b.gkeys, b.gvals, b.gkeys_sorted, b.gvals_sorted, b.gcap, s);    // padding (~0) sorts last
         }
         bh_merge_kernel<<<grid_m, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, n, b.gkeys_sorted, b.gvals_sorted, b.gcap,
                                                b.keys_merged, b.vals_merged, b.ctr);
@@ -330,7 +327,7 @@ int enqueue_bh_build(nbody_ctx* ctx)
     }
     BhWaitErrors werr{{nullptr, nullptr, nullptr}};
     if (!use_hipcub && !ranked) werr.p[0] = &b.sort_main.state->error;
-    if (!use_hipcub && !fused) { werr.p[1] = &b.scan_state->error; if (b.gcap > kBhSmallGhosts) werr.p[2] = &b.sort_ghost.state->error; }
+    if (!use_hipcub && !fused) werr.p[1] = &b.scan_state->error;
     const dim3 grid_c((b.tree.cap_internal + kBhBlock - 1) / kBhBlock);
     bh_nodes_kernel<<<grid_c, blk, 0, s>>>(b.keys_merged, b.vals_merged, b.cnt, b.base, b.owner, nm, ctx->m, ctx->px, ctx->py,
                                            b.tree, b.ctr, b.overflow_dev, fused ? b.keys_sorted : nullptr,
@@ -370,7 +367,7 @@ int enqueue_bh_walk(nbody_ctx* ctx, int advance)
                 HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.own_sort_tmp, b.own_sort_bytes, b.keys + sb, b.own_keys_sorted, b.vals + sb,
                                                            b.own_order, sc, 0, 64, ctx->stream));
             else
-                sort_pairs(b.sort_own, b.keys + sb, b.vals + sb, b.own_keys_sorted, b.own_order, sc, ctx->stream);
+                sort_pairs(b.sort_own, b.keys + sb, b.vals + sb, b.own_keys_sorted, b.own_order, sc, ctx->stream, true);
             w.order = b.own_order - sb;
         } else {
             w.order = b.vals_sorted;
@@ -584,9 +581,11 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
         b.gcap = n / 256 > 4096 ? n / 256 : 4096;
         const size_t nm = (size_t)n + (size_t)b.gcap;
         HIP_TRY_C(hipMalloc((void**)&b.gkeys, sizeof(uint64_t) * (size_t)b.gcap));
-        HIP_TRY_C(hipMalloc((void**)&b.gkeys_sorted, sizeof(uint64_t) * (size_t)b.gcap));
+        size_t gpow = 2;                                        // the sorted tie arrays: next power of two (bh_tie_fixpoint_sort_kernel)
+        while (gpow < (size_t)b.gcap) gpow <<= 1;
+        HIP_TRY_C(hipMalloc((void**)&b.gkeys_sorted, sizeof(uint64_t) * gpow));
         HIP_TRY_C(hipMalloc((void**)&b.gvals, sizeof(int) * (size_t)b.gcap));
-        HIP_TRY_C(hipMalloc((void**)&b.gvals_sorted, sizeof(int) * (size_t)b.gcap));
+        HIP_TRY_C(hipMalloc((void**)&b.gvals_sorted, sizeof(int) * gpow));
         HIP_TRY_C(hipMalloc((void**)&b.gfx, sizeof(unsigned) * (size_t)b.gcap));
         HIP_TRY_C(hipMalloc((void**)&b.gfy, sizeof(unsigned) * (size_t)b.gcap));
         HIP_TRY_C(hipMalloc((void**)&b.gld, sizeof(int) * (size_t)b.gcap));
@@ -634,16 +633,17 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
             if ((e = hipMemset(sbuf.state, 0, sizeof(SortState))) != hipSuccess) return e;
             const unsigned one = 1;
             if ((e = hipMemcpy(&sbuf.state->epoch, &one, sizeof(one), hipMemcpyHostToDevice)) != hipSuccess) return e;
-            sbuf.tiles = sort_tiles(count);
-            const size_t lb = sizeof(unsigned long long) * (size_t)sbuf.tiles * kSortBins;
+            sbuf.tiles = (count + kSortBlock * 8 - 1) / (kSortBlock * 8);           // the smaller tile: enough for either
+            const size_t lb = sizeof(unsigned long long) * sort_look_words(sbuf.tiles);
             if ((e = hipMalloc((void**)&sbuf.look, lb)) != hipSuccess) return e;
             if ((e = hipMemset(sbuf.look, 0, lb)) != hipSuccess) return e;
+            if ((e = hipMalloc((void**)&sbuf.hist_part, sort_hist_part_bytes())) != hipSuccess) return e;
+            if ((e = hipMalloc((void**)&sbuf.queue, sizeof(int) * kSortQueueCap)) != hipSuccess) return e;
             if (tmp_k) { sbuf.tmp_k = tmp_k; sbuf.tmp_v = tmp_v; return hipSuccess; }
             if ((e = hipMalloc((void**)&sbuf.tmp_k, sizeof(uint64_t) * (size_t)count)) != hipSuccess) return e;
             return hipMalloc((void**)&sbuf.tmp_v, sizeof(int) * (size_t)count);
         };
         HIP_TRY_C(make_sort(b.sort_main, n, b.keys_merged, b.vals_merged));      // the merged arrays are written after the sort
-        if (b.gcap > kBhSmallGhosts) HIP_TRY_C(make_sort(b.sort_ghost, b.gcap, nullptr, nullptr));
         {
             HIP_TRY_C(hipMalloc((void**)&b.scan_state, sizeof(ScanState)));
             const ScanState s0{1u, 0, 0, 0};
@@ -685,8 +685,8 @@ void nbody_destroy(nbody_ctx* ctx)
                         b.tree.depth, b.tree.self, b.tree.pend, b.rank, b.rank_done, b.tie_first_sorted, b.body4, b.ctr, b.tie, b.owner, b.gfx, b.gfy, b.gld, b.pld, b.glo, b.ghi, b.gpos, b.tie_table, b.sort_tmp, b.scan_tmp, b.gkeys, b.gkeys_sorted, b.gvals,
                         b.gvals_sorted, b.keys_merged, b.vals_merged, b.gsort_tmp, b.grp_visits, b.grp_accepts,
                         b.own_keys_sorted, b.own_order, b.own_sort_tmp,
-                        b.sort_main.state, b.sort_main.look, b.sort_ghost.state, b.sort_ghost.look, b.sort_ghost.tmp_k, b.sort_ghost.tmp_v,
-                        b.sort_own.state, b.sort_own.look, b.sort_own.tmp_k, b.sort_own.tmp_v, b.scan_state, b.scan_look};
+                        b.sort_main.state, b.sort_main.look, b.sort_main.hist_part, b.sort_main.queue,
+                        b.sort_own.state, b.sort_own.look, b.sort_own.hist_part, b.sort_own.queue, b.sort_own.tmp_k, b.sort_own.tmp_v, b.scan_state, b.scan_look};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (b.overflow_host) (void)hipHostFree(b.overflow_host);
@@ -1285,7 +1285,8 @@ int nbody_accel_noalloc(int32_t num_bodies, const float* dev_m, const float* dev
 }
 
 // Parity hook for bh_sort.hip.h: the build's own device sort on host arrays (tests compare with a stable host sort).
-int nbody_sort_pairs_u64(const uint64_t* keys, const int32_t* vals, int32_t n, uint64_t* out_keys, int32_t* out_vals, int32_t repeats)
+int nbody_sort_pairs_u64(const uint64_t* keys, const int32_t* vals, int32_t n, uint64_t* out_keys, int32_t* out_vals, int32_t repeats,
+                         int32_t truncated)
 {
     if (!keys || !vals || !out_keys || !out_vals || n < 1 || repeats < 1) return fail(NBODY_ERR_INVALID, "nbody_sort_pairs_u64: bad argument");
     int ndev = 0;
@@ -1303,14 +1304,16 @@ int nbody_sort_pairs_u64(const uint64_t* keys, const int32_t* vals, int32_t n, u
         HIP_TRY(hipMemset(sb.state, 0, sizeof(SortState)));
         const unsigned one = 1;
         HIP_TRY(hipMemcpy(&sb.state->epoch, &one, sizeof(one), hipMemcpyHostToDevice));
-        const size_t lb = sizeof(unsigned long long) * (size_t)sort_tiles(n) * kSortBins;
+        const size_t lb = sizeof(unsigned long long) * sort_look_words((n + kSortBlock * 8 - 1) / (kSortBlock * 8));
         HIP_TRY(hipMalloc((void**)&sb.look, lb));
         HIP_TRY(hipMemset(sb.look, 0, lb));
+        HIP_TRY(hipMalloc((void**)&sb.hist_part, sort_hist_part_bytes()));
+        HIP_TRY(hipMalloc((void**)&sb.queue, sizeof(int) * kSortQueueCap));
         HIP_TRY(hipMemcpy(dk, keys, kb, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(dv, vals, vb, hipMemcpyHostToDevice));
         for (int r = 0; r < repeats; ++r) {                       // repeats: the state (epochs, tickets, histograms) carries over
             HIP_TRY(hipMemsetAsync(ok, 0xA5, kb, nullptr));
-            sort_pairs(sb, dk, dv, ok, ov, n, nullptr);
+            sort_pairs(sb, dk, dv, ok, ov, n, nullptr, truncated != 0);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
@@ -1320,12 +1323,12 @@ int nbody_sort_pairs_u64(const uint64_t* keys, const int32_t* vals, int32_t n, u
         return NBODY_OK;
     };
     int rc = run();
-    void* ptrs[] = {dk, ok, dv, ov, sb.tmp_k, sb.tmp_v, sb.state, sb.look};
+    void* ptrs[] = {dk, ok, dv, ov, sb.tmp_k, sb.tmp_v, sb.state, sb.look, sb.hist_part, sb.queue};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
 #ifdef NBODY_WIDE_TIMING
     if (rc == NBODY_OK && host_state.dbg_cnt) {
-        const char* nm[] = {"plan+ticket", "loads", "rank", "bins+scans", "look-back", "LDS scatter", "global scatter"};
+        const char* nm[] = {"plan+ticket", "loads", "rank", "bins+scan", "tile tree", "LDS scatter", "global scatter"};
         for (int q = 0; q < 7; ++q)
             std::fprintf(stderr, "[sort] n=%d up to '%s': mean %.2f us  max %.2f us (per live tile, since the workgroup started)\n", n, nm[q],
                          (double)host_state.dbg_sum[q] / (double)host_state.dbg_cnt * 0.01, (double)host_state.dbg_max[q] * 0.01);

@@ -78,3 +78,40 @@ def test_plummer_4m_tree_and_sampled_walk_equal_the_oracle(nb, O):
     O.lib().oracle_bh_accel(ot.h, nt, b.posX, b.posY, b.radius, theta, 0, 8, ox, oy, oc)
     assert cnt == dict(visits=int(oc[0]), accepts=int(oc[1]))
     assert np.array_equal(ax[:nt], ox[:nt].astype(np.float32)) and np.array_equal(ay[:nt], oy[:nt].astype(np.float32))
+
+
+def test_more_split_line_bodies_than_the_lds_sort_holds(nb, O):
+    """2^21 bodies of which 6000 sit exactly on the root's vertical split line (x = 0): more second instances than
+    bh_tie_fixpoint_sort_kernel sorts in LDS (4096), so its device-memory network runs.  The tree (every node), the
+    counters and the accelerations of the first 4096 targets equal the build with rocPRIM's sort and scan
+    (NBODY_BH_HIPCUB) bit for bit; node count and root record equal the oracle's serially inserted tree."""
+    import ctypes as C
+    import os
+    n, nt = 1 << 21, 4096
+    b = O.init_disc(n, seed=99)
+    rng = np.random.default_rng(5)
+    on = rng.choice(n, size=6000, replace=False)
+    b.posX[on] = 0.0
+    b.posY[on] = np.linspace(-399.0, 399.0, len(on)).astype(np.float32)      # distinct: coincident bodies recurse without end
+    got = {}                                                                 # in the reference (and in the oracle that follows it)
+    for name in ("own", "rocprim"):
+        os.environ.pop("NBODY_BH_HIPCUB", None)
+        if name == "rocprim":
+            os.environ["NBODY_BH_HIPCUB"] = "1"
+        try:
+            with nb.NBodySim(n, theta=1.0, useBarnesHut=True, shard=(0, nt)) as sim:
+                sim.upload(*b.arrays())
+                sim.compute_accel().sync()
+                got[name] = (sim.accel(), sim.bh_tree(), sim.bh_counters())
+        finally:
+            os.environ.pop("NBODY_BH_HIPCUB", None)
+    (ax, ay), tree, cnt = got["own"]
+    (rx, ry), rtree, rcnt = got["rocprim"]
+    assert cnt == rcnt and np.array_equal(ax, rx) and np.array_equal(ay, ry)
+    assert len(tree) == len(rtree) and tree.tobytes() == rtree.tobytes()
+    ot = O.Tree(n).build(b, 400.0)
+    assert len(tree) == ot.nodes_used
+    oroot = np.frombuffer((C.c_char * 48).from_address(O.lib().oracle_tree_pool(ot.h)), dtype=O.NODE_DTYPE)[0]
+    for f in ("mass", "comX", "comY"):
+        assert tree[0][f] == oroot[f], f
+    assert float(tree[0]["mass"]) > 1000.0 * (n + 5900)          # the 6000 are in the tree twice (benchmark.cpp:83-85)

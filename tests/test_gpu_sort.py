@@ -9,13 +9,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def check(nb, keys, repeats=1):
+def check(nb, keys, repeats=1, truncated=(False, True)):
     keys = np.ascontiguousarray(keys, np.uint64)
     vals = np.arange(len(keys), dtype=np.int32)
-    ok, ov = nb.sort_pairs_u64(keys, vals, repeats)
     order = np.argsort(keys, kind="stable")
-    assert np.array_equal(ov, order.astype(np.int32)), f"n={len(keys)}: first difference at {np.nonzero(ov != order)[0][:4]}"
-    assert np.array_equal(ok, keys[order])
+    for tr in truncated:                       # the full 8-sweep sort and the build's form: 5 sweeps + run kernels
+        ok, ov = nb.sort_pairs_u64(keys, vals, repeats, truncated=tr)
+        assert np.array_equal(ov, order.astype(np.int32)), f"n={len(keys)} truncated={tr}: first difference at {np.nonzero(ov != order)[0][:4]}"
+        assert np.array_equal(ok, keys[order])
 
 
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 2047, 2048, 2049, 4096, 12289, 100_003, 1 << 20, (1 << 21) + 1, 5_000_017])
@@ -54,3 +55,24 @@ def test_path_keys_of_the_disc_many_sorts_on_one_state(nb, O):
     keys = np.zeros(n, np.uint64)
     O.lib().oracle_path_keys(n, 400.0, b.posX, b.posY, keys)
     check(nb, keys, repeats=5)
+
+
+@pytest.mark.parametrize("n,prefixes", [(200_000, 150_000), (200_000, 3000), (300_000, 7), (70_000, 1), (1_500_000, 40)])
+def test_runs_of_equal_prefixes(nb, n, prefixes):
+    """The truncated form sweeps bits 24-63 only; pairs that agree there are finished by the run kernels: short runs
+    (many prefixes: runs of 1-5), runs around the 32-pair limit of the insertion sort, and long runs that one wave sorts
+    (a few prefixes; one prefix = the whole input is one run)."""
+    rng = np.random.default_rng(n + prefixes)
+    pre = rng.integers(0, 2 ** 38, size=prefixes, dtype=np.uint64)
+    keys = (pre[rng.integers(0, prefixes, size=n)] << np.uint64(24)) | rng.integers(0, 2 ** 24, size=n, dtype=np.uint64)
+    keys[::5] = keys[1::5][:len(keys[::5])]                       # and equal FULL keys: stability inside the runs
+    check(nb, keys, repeats=2)
+
+
+def test_run_lengths_around_the_insertion_limit(nb):
+    rng = np.random.default_rng(33)
+    parts = []
+    for length in list(range(1, 40)) * 20:
+        parts.append((np.uint64(len(parts) + 1) << np.uint64(24)) | rng.integers(0, 2 ** 24, size=length, dtype=np.uint64))
+    keys = np.concatenate(parts)
+    check(nb, keys[rng.permutation(len(keys))])
