@@ -1104,14 +1104,37 @@ __global__ __launch_bounds__(kBhBlock) void bh_com_kernel(BhTree t, const BhCoun
 // version) -> 22 us, N = 10^6 143 (31 launches) -> 109 us; above ~2 x 10^6 bodies the per-depth launches win again
 // (their loads hit the L2), so the host switches there.
 //
-// Visibility across workgroups, which may sit on different XCDs (one L2 each): the children's results are written
-// with device-scope stores and read with device-scope loads (`sc1`: write through to / read from the level all XCDs
-// share), the stores are waited for (s_waitcnt vmcnt(0)) before the count-off atomic is issued, and the parent's loads
-// are issued after that atomic has returned.  That is the LLVM AMDGPU memory model's agent-scope release/acquire
-// sequence for gfx942/gfx950 minus its two cache-wide operations (buffer_wbl2 / buffer_inv), which exist for data
-// written or read with ORDINARY stores and loads — there is none here.  With them (a plain __threadfence() on either
-// side of the atomic) the N = 10^6 build takes 3.2 ms instead of 0.52: every fence writes back / invalidates the whole
-// L2 for everybody.
+// Visibility across workgroups, which may sit on different XCDs (one L2 each).  The hand-off is, per child:
+//   (1) the child's record {comX, comY | mass} is written ONLY by agent-scope relaxed atomic stores (8 B + 4 B), which
+//       gfx950 emits as `global_store ... sc1`: they write through the XCD's L2 and leave no line behind in it;
+//   (2) the storing wave waits for them (s_waitcnt vmcnt(0)) BEFORE (3) it issues the count-off, an agent-scope
+//       atomic read-modify-write on the parent's counter;
+//   (4) the lane whose atomic returned 1 — and nobody else — reads the four children's records, AFTER that return,
+//       ONLY with agent-scope relaxed atomic loads (`global_load ... sc1`: served below the L1, never from it).
+// Why this is enough, on paper:
+//   * LLVM AMDGPU memory model (AMDGPUUsage, "Memory Model", gfx940/gfx942 table, which gfx950 shares): an agent-scope
+//     RELEASE is `buffer_wbl2 sc1` + `s_waitcnt vmcnt(0)` before the atomic — the write-back exists to push ORDINARY
+//     (non-sc1) dirty lines of the XCD's L2 out to where other XCDs can see them; the waitcnt orders earlier stores
+//     before the atomic.  An agent-scope ACQUIRE is the atomic + `s_waitcnt vmcnt(0)` + `buffer_inv sc1` — the
+//     invalidate exists so that LATER ORDINARY loads do not hit stale L1/L2 lines.  Steps (2)/(3) are the release
+//     without the write-back, steps (3)/(4) the acquire without the invalidate; both omissions are sound exactly
+//     because no ordinary store (1) or ordinary load (4) ever touches the handed-off bytes inside this launch.  Every
+//     other word the climb reads (t.self, child records of leaf-only cells) was written by the PREVIOUS kernel.
+//   * /opt/skills/guides/MI355X_MICROARCH.md, "Valid forms besides Guideline 16's R1/R2", Consumer bullet: `sc1` loads
+//     to registers may replace the acquire when (1) EVERY load of the handed-off bytes is such a load, (2) the producer
+//     stored every one of those bytes `sc1`, (3) every storing wave ran s_waitcnt vmcnt(0) after its stores and the
+//     counter add comes after that wait, (4) the hand-off matches the measured table: its first row — "ONE lane ...
+//     an agent-scope atomic add ... all those lanes add to ONE unsharded counter, the workgroup whose add came last,
+//     told by the value its add returned; the wave that added last loads only after its add has returned; 4-, 8- or
+//     16-B sc1 stores and loads" — is this protocol with a lane signalling for its own stores only.  The guide marks the
+//     table "measured on gfx950 / ROCm 7.2, not an architectural guarantee"; so the result is also CHECKED: the
+//     determinism test forces every parent and its children onto different workgroups (kScatter below: consecutive
+//     cells go to consecutive workgroups, which the dispatcher deals round-robin over the 8 XCDs) and compares all
+//     nodes bit for bit with the per-depth kernel, whose hand-offs are kernel boundaries
+//     (tests/test_gpu_bh.py::test_centre_of_mass_pass_is_deterministic_over_repeated_builds).
+// With the two cache-wide operations (a plain __threadfence() on either side of the atomic) the N = 10^6 build takes
+// 3.2 ms instead of 0.52: every fence writes back / invalidates the whole L2 for everybody.  The per-depth kernel
+// stays in the tree as the fallback (NBODY_BH_CLIMB_MAX=0).
 // kAgentLoads = false: the cell's children are all leaves, written by the PREVIOUS kernel — ordinary (cached) loads do.
 template <bool kAgentLoads>
 __device__ __forceinline__ void bh_com_cell_agent(const BhTree& t, int c)
@@ -1150,10 +1173,12 @@ __device__ __forceinline__ void bh_com_cell_agent(const BhTree& t, int c)
     __hip_atomic_store(reinterpret_cast<unsigned*>(rec + 1), __float_as_uint(ms), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(kBhBlock) void bh_com_climb_kernel(BhTree t, const BhCounters* __restrict__ ctr)
+// scatter != 0 (test switch NBODY_BH_CLIMB_SCATTER): cell c = thread * workgroups + workgroup instead of workgroup * 256 +
+// thread, so that the consecutive ids of a subtree — parent and children — sit in DIFFERENT workgroups on different XCDs.
+__global__ __launch_bounds__(kBhBlock) void bh_com_climb_kernel(BhTree t, const BhCounters* __restrict__ ctr, int scatter)
 {
     const int I = ctr->internal;
-    int c = blockIdx.x * kBhBlock + threadIdx.x;
+    int c = scatter ? (int)(threadIdx.x * gridDim.x + blockIdx.x) : (int)(blockIdx.x * kBhBlock + threadIdx.x);
     if (c >= I) return;
     if (t.pend[c] != -1) return;                   // has internal children: the last of them to finish takes it
     for (int hop = 0; hop <= kBhLevels; ++hop) {

@@ -337,7 +337,7 @@ int enqueue_bh_build(nbody_ctx* ctx)
     const char* climb_env = std::getenv("NBODY_BH_CLIMB_MAX");          // developer/test switch, read per enqueue
     const int climb_max = climb_env ? std::atoi(climb_env) : kBhClimbMax;
     if (n <= climb_max) {
-        bh_com_climb_kernel<<<grid_c, blk, 0, s>>>(b.tree, b.ctr);
+        bh_com_climb_kernel<<<grid_c, blk, 0, s>>>(b.tree, b.ctr, std::getenv("NBODY_BH_CLIMB_SCATTER") ? 1 : 0);
     } else {
         const dim3 grid_com((unsigned)((b.tree.cap_internal + 4 * kBhBlock - 1) / (4 * kBhBlock)));
         for (int d = kBhLevels - 1; d >= 0; --d)

@@ -301,6 +301,29 @@ def test_centre_of_mass_pass_is_deterministic_over_repeated_builds(nb, O):
             assert np.array_equal(rec, first)
 
 
+@pytest.mark.parametrize("n", [10_000, 300_000, 1_500_000])
+def test_centre_of_mass_hand_off_across_xcds(nb, O, n, monkeypatch):
+    """The one-launch climb hands a child's record to whoever evaluates the parent with sc1 stores, a counter add and
+    sc1 loads, without the cache-wide release/acquire operations (bh_tree.hip.h: the argument and its sources).  By
+    default a parent and its children mostly sit in ONE workgroup, where even a broken hand-off would go unnoticed;
+    NBODY_BH_CLIMB_SCATTER deals consecutive cells to consecutive workgroups — round-robin over the 8 XCDs — so that
+    nearly every hand-off crosses workgroups and XCDs.  20 scattered builds, every node bit-equal to the per-depth
+    kernel's (NBODY_BH_CLIMB_MAX=0), whose hand-offs are kernel boundaries."""
+    b = O.init_plummer(n, scale=50.0, seed=11)
+    with nb.NBodySim(n, useBarnesHut=True, useParallel=False) as sim:
+        sim.upload(*b.arrays())
+        monkeypatch.setenv("NBODY_BH_CLIMB_MAX", "0")
+        sim.compute_accel().sync()
+        t = sim.bh_tree()
+        ref = np.stack([t["mass"], t["comX"], t["comY"]]).view(np.uint32)
+        monkeypatch.delenv("NBODY_BH_CLIMB_MAX")
+        monkeypatch.setenv("NBODY_BH_CLIMB_SCATTER", "1")
+        for _ in range(20):
+            sim.compute_accel().sync()
+            t = sim.bh_tree()
+            assert np.array_equal(np.stack([t["mass"], t["comX"], t["comY"]]).view(np.uint32), ref)
+
+
 @pytest.mark.parametrize("n", [255, 5000, 12288])
 def test_rank_sort_equals_the_device_radix_sort(nb, O, n, monkeypatch):
     """Up to 12 288 bodies the (key, body) sort is bh_ranksort_kernel (brute-force ranking, one launch), above that
