@@ -831,12 +831,13 @@ void drop_step_graph(nbody_ctx* ctx)
     ctx->step_graph_stream = nullptr;
 }
 
-// Capture one step into a hipGraph (both step kinds: the Barnes-Hut step is 6-50 launches, the naive step two — at
-// the reference's default N = 10 000 those two are launch-bound; skipped while per-kernel event timing is on, because
-// event pairs recorded inside a capture cannot be queried).  Any failure falls back to eager launches for good.
+// Capture one step into a hipGraph (Barnes-Hut only; skipped while per-kernel event timing is on, because event pairs
+// recorded inside a capture cannot be queried).  Any failure falls back to eager launches for good.  The naive step's
+// two launches are NOT captured: measured back to back at N = 10 000 (tools/naive_small_time.py,
+// profiles/r3_naive_small_sizes.txt) the graph replays them in 35.9 us per step, the stream issues them in 31.4.
 bool ensure_step_graph(nbody_ctx* ctx)
 {
-    if (ctx->prof.on || ctx->graph_failed || std::getenv("NBODY_NO_GRAPH")) return false;
+    if (!ctx->cfg.use_barnes_hut || ctx->prof.on || ctx->graph_failed || std::getenv("NBODY_NO_GRAPH")) return false;
     if (ctx->step_graph && ctx->step_graph_stream == ctx->stream) return true;
     drop_step_graph(ctx);
     hipGraph_t graph = nullptr;
