@@ -338,6 +338,22 @@ def main():
                                  "convention); counters show it VALU-issue-bound at N=1e6 (78 VALU instructions per wave "
                                  "iteration, 85 % L2 hits, profiles/README.md), so the HBM fraction is a floor, not a target"},
         }
+        # The unit that actually bounds the walk: VALU issue.  Counters cannot be read from inside the process, so the
+        # instruction count of this launch is its LIVE group-visit count x the VALU instructions per group-visit and the
+        # issue cycles per VALU instruction that the committed counter passes measured for that kernel
+        # (SQ_INSTS_VALU / visits, 4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU):
+        #   bh_walk_kernel       10.3 VALU per group-visit, 4.2 cycles each (profiles/r2c_bh_n1m_walk_pmc.txt, N = 1e6;
+        #                        9.9 and 4.2 at N = 2^24 theta 0.5, profiles/r3_pmc_bh16m_kernels.txt)
+        #   bh_walk_quad_kernel  24.9 VALU per group-visit, 4.1 cycles each (profiles/r3_pmc_bh10k_kernels.txt, N = 1e4)
+        # against 1024 SIMDs x the clock (amdsmi reading of this run when there is one, else 2.4 GHz).
+        vpv, cpi = (24.9, 4.13) if walk_kernel == "bh_walk_quad_kernel" else (10.3, 4.2)
+        ghz = (clock.get("gfx_mhz") or 2400.0) / 1e3 if clock else 2.4
+        used = cnt["visits"] * vpv * cpi / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
+        line["roofline_valu"] = {"bound": "valu-issue", "achieved": used, "peak": 1024 * ghz, "unit": "G SIMD-cycles/s",
+                                 "frac": used / (1024 * ghz), "kernel": walk_kernel, "kernel_ms": walk_ms,
+                                 "valu_insts_per_group_visit": vpv, "issue_cycles_per_valu_inst": cpi,
+                                 "note": "fraction of all SIMD issue cycles spent issuing VALU instructions; per-visit figures are "
+                                         "calibrated from committed rocprofv3 --pmc passes, the visit count and the duration are live"}
         if world == 1 and n == 1_000_000 and args.theta == 1.0 and not args.bh_fast_math:
             line["roofline"]["traffic"] = 2 * 1358941.2 * 1024          # FETCH_SIZE KiB x2 (gfx950), per walk launch
             line["roofline"]["traffic_source"] = "profiles/r1_bh_n1m_pmc_summary.csv (separate rocprofv3 --pmc passes; not live)"
@@ -383,13 +399,13 @@ def main():
         line["roofline_integrate"] = {"bound": "hbm", "achieved": i_gbs, "peak": 8000.0, "unit": "GB/s", "frac": i_gbs / 8000.0,
                                       "traffic": None, "kernel": "integrate_kernel", "kernel_ms": i_ms,
                                       "launches": int(integ_launches),
-                                      "note": "hipEvent pairs add ~4 us to a kernel this short: rocprofv3 shows 18.9 us = 5.8 TB/s "
-                                              "for the same launch (profiles/README.md)"}
+                                      "note": "hipEvent pairs add ~3 us to a kernel this short: rocprofv3 shows 21.1 us = 5.2 TB/s "
+                                              "for the same launch (profiles/r3_naive_n1m_kernel_stats.csv)"}
         if world == 1 and n == 1 << 20 and info["j_slices"] == 8:
             # HBM bytes per force launch from the committed PMC passes of this very command (FETCH_SIZE KiB x2 on
             # gfx950 + WRITE_SIZE KiB); counters cannot be read from inside the process, so this is not live
-            line["roofline"]["traffic"] = (2 * 32807.1 + 65536.0) * 1024
-            line["roofline"]["traffic_source"] = "profiles/r2_naive_n1m_pmc_summary.csv (bytes per launch; algorithmic: 8.4 MB read + 67.1 MB of j-slice partials written)"
+            line["roofline"]["traffic"] = (2 * 32806.3 + 65536.0) * 1024
+            line["roofline"]["traffic_source"] = "profiles/r3_naive_n1m_pmc_summary.txt (bytes per launch; algorithmic: 8.4 MB read + 67.1 MB of j-slice partials written)"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -112,6 +112,9 @@ __device__ __forceinline__ f2 pair_weight(const f2 d2, const f2 ci, const Src<V>
 // later one has at least one instruction between it and the last v_rsq_f32, which the compiler can only have placed
 // before the statement — so one s_nop serves the block instead of one per multiply (round 2: 8 per iteration, priced at
 // 0.7 % by profiles/r1_clamp_variants_ab.txt).  Outputs are early-clobber: w[0] is written while inv[1..] are unread.
+#ifndef NBODY_FORCE_UNROLL
+#define NBODY_FORCE_UNROLL 2     // inner iterations per loop body (4 measured: see profiles/r3_force_unroll_ab.txt)
+#endif
 #ifndef NBODY_CLAMP_BLOCK
 #define NBODY_CLAMP_BLOCK 1
 #endif
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(kBlock, MINW) void force_naive_kernel(const ForceAr
         for (int k = 0; k < KP; ++k) { tx[k] = f2{0.0f, 0.0f}; ty[k] = f2{0.0f, 0.0f}; }
 
         const S* __restrict__ t = tile[buf];
-#pragma unroll 2
+#pragma unroll NBODY_FORCE_UNROLL
         for (int jj = 0; jj < TJ; jj += JU) {
             S s[JU];
             f2 dx[G], dy[G], d2[G], f[G];
