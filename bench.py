@@ -243,7 +243,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         args.gpus = world
-    watchdog(120)                                  # process group + context + upload
+    watchdog(300)                                  # process group + context + upload (a first RCCL bootstrap on 8 GPUs can take a minute)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     # one rank per GPU; NBODY_DIST_BACKEND=gloo + fewer GPUs than ranks is the single-GPU rehearsal of the N>1 path
@@ -278,7 +278,7 @@ def main():
 
     sampler = ClockSampler(local_rank).start() if rank == 0 else None
     # warm-up + timed steps: ~0.2 s per naive step at N = 2^20 on one GPU
-    watchdog(120 + int(2.0 * (args.steps + args.warmup) * max(1.0, (n / float(1 << 20)) ** 2) / world))
+    watchdog(300 + int(2.0 * (args.steps + args.warmup) * max(1.0, (n / float(1 << 20)) ** 2) / world))
     barrier()
     t_load = time.perf_counter()
     sim.step(args.warmup)

@@ -46,15 +46,23 @@ class NBodyError(RuntimeError):
 
 
 _lib = None
+_torch_first = None          # was PyTorch already imported when the library was loaded?  (see lib())
 _f32p = C.POINTER(C.c_float)
 
 
 def lib():
     """Load libnbody_amd.so (raises if it has not been built — no fallback)."""
-    global _lib
+    global _lib, _torch_first
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} not found: build it with `make lib` (hipcc, gfx950)")
+        # PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  Whichever runtime a process loads FIRST serves every
+        # later user (same SONAME); but if this library comes first it binds /opt/rocm's runtime, torch then brings up
+        # its own beside it, and the second one finds no GPU ("No HIP GPUs are available") or aborts on a stream of the
+        # other.  A process that uses both must import torch first (bench.py and tests/conftest.py do);
+        # torch_interop_ok() lets the torch-facing code (sharded.py) refuse loudly otherwise.
+        import sys
+        _torch_first = "torch" in sys.modules
         L = C.CDLL(LIB_PATH)
         L.nbody_default_config.argtypes = [C.POINTER(Config)]
         L.nbody_default_config.restype = None
@@ -106,6 +114,11 @@ def default_config():
     cfg = Config()
     lib().nbody_default_config(C.byref(cfg))
     return cfg
+
+
+def torch_interop_ok():
+    """False when the library was loaded BEFORE torch in this process (two HIP runtimes: see lib())."""
+    return _lib is None or bool(_torch_first)
 
 
 def shard_range(num_bodies, nranks, rank):

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(1024) void sort_plan_kernel(const unsigned* __restr
     if (tid < kSortBins) st->base[d][tid] = before + incl - tot;
     if (tid == 0) st->live_d[d] = (dead || d < first) ? 0u : 1u;       // positions below `first` are left to sort_fix_runs_kernel
     if (d == 0 && tid < kSortDigits) st->tickets[tid] = 0;
-    if (d == 0 && tid == 0) st->long_runs = 0;
+    if (d == 0 && tid == 0) { st->long_runs = 0; st->error = 0; }     // the flag describes THIS sort (its reader comes after it)
 }
 
 inline size_t sort_look_words(int tiles) { return (size_t)tiles * kSortBins; }

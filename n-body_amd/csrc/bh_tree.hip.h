@@ -662,6 +662,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_cells_scan_kernel(const uint64_t*
     if (tid == 0) s_tile = atomicAdd(&ss->ticket, 1);
     __syncthreads();
     const int tile = s_tile;
+    if (tile == 0 && tid == 0) ss->error = 0;       // the flag describes THIS scan (a wait gives up after ~0.3 s: long after this)
     if ((long long)tile * T < nm) {
         const int w0 = tile * T + wave * (64 * R);
         uint64_t kc[R], ke[R];

@@ -45,7 +45,7 @@ enum ForceVariant : int { kScaled = 1, kUniform = 2, kPerBody = 3, kExact = 4 };
 
 // Sources per LDS tile: the big tile amortises the per-tile barrier at large N; the small one lets a
 // small N be cut into enough j-slices to fill 256 CUs (N = 10 000 -> 40 slices of 256 sources).
-constexpr int kTileSmall = 256;
+constexpr int kTileSmall = 512;      // small launches: the tile is swept only as far as the slice goes (kDyn), any multiple of 8
 template <int V> struct Tile { static constexpr int kTileBig = (V == kScaled || V == kUniform) ? 2048 : 1024; };
 
 struct ForceArgs {
@@ -58,7 +58,7 @@ struct ForceArgs {
     int n;                          // number of sources
     int i_begin, i_end;             // targets [i_begin, i_end)
     int i_stride;                   // row pitch of pax/pay (>= i_end - i_begin)
-    int j_per_slice;                // multiple of the variant's tile size
+    int j_per_slice;                // multiple of the variant's big tile size, or (small tile) of 8
     float pre_scale;                // kScaled: 1/R (power of two, exact); otherwise 1
     float uni_c;                    // kUniform: the common 1/(R^2+soft2)
     float out_scale;                // kScaled: m/R^2, kUniform: m, otherwise 1
@@ -148,7 +148,8 @@ template <> __device__ __forceinline__ void clamp_square_block<8>(const f2 (&inv
 // i_begin + b*kBlock*K + k*kBlock + tid (lane-contiguous => coalesced) against the sources of slice y.
 // K targets per lane are held as K/2 packed pairs; JU sources are processed per inner iteration in
 // stage order (all dx/dy, all d2, all rsq, ...) so no dependent instructions sit back to back.
-template <int V, int K, int JU, int TJ, int MINW = 4>
+// kDyn (the small tile): j_per_slice is any multiple of 2 * JU, and a tile is swept only up to the slice's (padded) end.
+template <int V, int K, int JU, int TJ, int MINW = 4, bool kDyn = false>
 __global__ __launch_bounds__(kBlock, MINW) void force_naive_kernel(const ForceArgs a)
 {
     using S = Src<V>;
@@ -217,8 +218,11 @@ __global__ __launch_bounds__(kBlock, MINW) void force_naive_kernel(const ForceAr
         for (int k = 0; k < KP; ++k) { tx[k] = f2{0.0f, 0.0f}; ty[k] = f2{0.0f, 0.0f}; }
 
         const S* __restrict__ t = tile[buf];
-#pragma unroll NBODY_FORCE_UNROLL
-        for (int jj = 0; jj < TJ; jj += JU) {
+        int cnt = TJ;
+        if constexpr (kDyn) {
+            cnt = min(TJ, j_begin + a.j_per_slice - j0);       // padding sources (far away, massless) fill the rest of the slice
+        }
+        auto iteration = [&](const int jj) {
             S s[JU];
             f2 dx[G], dy[G], d2[G], f[G];
 #pragma unroll
@@ -254,6 +258,13 @@ __global__ __launch_bounds__(kBlock, MINW) void force_naive_kernel(const ForceAr
                     tx[k] = __builtin_elementwise_fma(dx[u * KP + k], f[u * KP + k], tx[k]);
                     ty[k] = __builtin_elementwise_fma(dy[u * KP + k], f[u * KP + k], ty[k]);
                 }
+                };
+        if constexpr (kDyn) {
+            // dynamic trip count: unrolled by hand (the optimizer will not unroll a loop whose count it cannot divide)
+            for (int jj = 0; jj < cnt; jj += 2 * JU) { iteration(jj); iteration(jj + JU); }
+        } else {
+#pragma unroll NBODY_FORCE_UNROLL
+            for (int jj = 0; jj < TJ; jj += JU) iteration(jj);
         }
 #pragma unroll
         for (int k = 0; k < KP; ++k) { AX[k] += tx[k]; AY[k] += ty[k]; }

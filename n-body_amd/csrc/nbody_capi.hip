@@ -192,8 +192,8 @@ void launch_force_k(int K, int tile, const ForceArgs& a, dim3 grid, hipStream_t 
     constexpr int JU = 4;
     constexpr int kBig = Tile<V>::kTileBig;
     if (tile == kTileSmall) {
-        if (K == 4) force_naive_kernel<V, 4, JU, kTileSmall><<<grid, dim3(kBlock), 0, s>>>(a);
-        else        force_naive_kernel<V, 2, JU, kTileSmall><<<grid, dim3(kBlock), 0, s>>>(a);
+        if (K == 4) force_naive_kernel<V, 4, JU, kTileSmall, 4, true><<<grid, dim3(kBlock), 0, s>>>(a);
+        else        force_naive_kernel<V, 2, JU, kTileSmall, 4, true><<<grid, dim3(kBlock), 0, s>>>(a);
     } else {
         if (K == 4) force_naive_kernel<V, 4, JU, kBig><<<grid, dim3(kBlock), 0, s>>>(a);
         else        force_naive_kernel<V, 2, JU, kBig><<<grid, dim3(kBlock), 0, s>>>(a);
@@ -432,10 +432,31 @@ ForcePlan make_force_plan(int n, int nt, int variant, int max_slices, int k_req 
     // tile: the big one unless that leaves fewer than HALF the slices wanted (N = 65 536: 32 slices of one 2048-source
     // tile run 0.8 % faster than 64 slices of four 256-source tiles and halve the partial rows, profiles/r3_force_plan_sweep.txt)
     p.tile = tile_req ? tile_req : (((n + want - 1) / want >= big / 2) ? big : kTileSmall);
-    const int max_slices_by_n = (n + p.tile - 1) / p.tile;
+    // granule of a slice: whole big tiles, or (small tile: swept only as far as the slice goes) 8 sources
+    const int gran = p.tile == kTileSmall ? 8 : p.tile;
+    const int min_per = p.tile == kTileSmall ? 64 : p.tile;
+    const int max_slices_by_n = (n + min_per - 1) / min_per;
     if (want > max_slices_by_n) want = max_slices_by_n;
     if (want < 1) want = 1;
-    p.j_per_slice = ((n + want - 1) / want + p.tile - 1) / p.tile * p.tile;
+    if (p.tile == kTileSmall && !slices_req && (long long)p.blocks_x * want < 4096) {
+        // Few workgroups (N = 10 000: 20 x 40 = 800 on 256 CUs): the launch ends with the CU that got the most of them, so
+        // what counts is rounds = ceil(workgroups / 256) x the sources of a slice, not their product — 800 workgroups are
+        // 4 rounds of 256 sources, 500 are 2 rounds of 400.  Model fitted to tools/naive_10k_slices.py
+        // (profiles/r3_naive_small_sizes.txt): cost = rounds x per-slice sources (/ 0.9 when one round leaves a single
+        // wave per SIMD) + 2 source-equivalents per slice (partial rows the Euler kernel sums, barriers).
+        double best = 1e30;
+        int best_s = want;
+        for (int sl = 1; sl <= want; ++sl) {
+            const int per = (((n + sl - 1) / sl) + gran - 1) / gran * gran;
+            if (per < min_per) break;
+            const int nsl = (n + per - 1) / per;
+            const int rounds = (int)(((long long)p.blocks_x * nsl + 255) / 256);
+            const double cost = rounds * per / (rounds == 1 ? 0.9 : 1.0) + 2.0 * nsl;
+            if (cost < best) { best = cost; best_s = sl; }
+        }
+        want = best_s;
+    }
+    p.j_per_slice = ((n + want - 1) / want + gran - 1) / gran * gran;
     p.slices = (n + p.j_per_slice - 1) / p.j_per_slice;
     return p;
 }

@@ -48,6 +48,9 @@ class ShardedSim:
                  useBarnesHut=False, exchange=None, **kw):
         import os
         import torch
+        if not pkg.torch_interop_ok():
+            raise RuntimeError("n-body_amd's library was loaded before `import torch` in this process: the two would run on "
+                               "two different HIP runtimes (torch wheels bundle their own).  Import torch first.")
         self.torch, self.dist = torch, dist
         self.rank, self.world, self.n = rank, world, num_bodies
         self.spans = [pkg.shard_range(num_bodies, world, r) for r in range(world)]

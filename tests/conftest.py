@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+try:                        # before anything loads libnbody_amd.so: a process that uses both must bring torch's bundled HIP
+    import torch  # noqa: F401   runtime up first (n-body_amd/__init__.py: lib()); some tests here hand torch streams and
+except ImportError:         # tensors to the library, and which test file happens to be collected first must not matter
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

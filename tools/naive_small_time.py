@@ -16,4 +16,4 @@ for n, steps in ((10000, 2000), (65536, 300), (131072, 100)):
             t0 = time.perf_counter(); sim.step(steps).sync(); dt = (time.perf_counter() - t0) / steps
             best = min(best, dt)
         info = sim.info()
-        print(f"N={n:7d}: {best*1e6:8.2f} us/step  {n*n/best/1e9:8.1f} G/s  {n*n/best/1e12*20/157.3*100:5.1f} % of peak  (slices {info['j_slices']}, graph {'off' if os.environ.get('NBODY_NO_GRAPH') else 'on'})", flush=True)
+        print(f"N={n:7d}: {best*1e6:8.2f} us/step  {n*n/best/1e9:8.1f} G/s  {n*n/best/1e12*20/157.3*100:5.1f} % of peak  (slices {info['j_slices']}, eager launches)", flush=True)
