@@ -334,3 +334,23 @@ def test_bench_fails_loudly_without_a_gpu():
     import __graft_entry__ as entry
     with pytest.raises(Exception, match="no HIP device|no CPU fallback"):
         entry.smoke()
+
+
+def test_bench_gpus_n_launches_its_own_ranks_and_fails_loudly_without_a_gpu(tmp_path):
+    """`python bench.py --gpus 2` from a plain interpreter (no torch.distributed.run around it): bench.py starts the ranks
+    itself.  Here there is no GPU, so every rank stops with the no-fallback message, and the
+    launcher must hand that failure on as a non-zero exit code without printing a result line."""
+    env = dict(os.environ, OMP_NUM_THREADS="1", NBODY_LAUNCH_TIMEOUT="150")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is visible: tests/test_gpu_multirank.py covers the launch that succeeds")
+    except ImportError:
+        pytest.skip("torch not importable")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--bodies", "4096"],
+                       env=env, capture_output=True, text=True, timeout=170, cwd=str(tmp_path))
+    assert r.returncode != 0
+    assert "no CPU fallback" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
