@@ -138,6 +138,7 @@ struct nbody_ctx {
         unsigned char* tie_first_sorted = nullptr;   //   first split-line level of each body, in sorted order [n]
         void *sort_tmp = nullptr, *scan_tmp = nullptr;
         size_t sort_bytes = 0, scan_bytes = 0;
+        bool hipcub_ready = false;                  // rocPRIM scratch allocated (context created with NBODY_BH_HIPCUB set)
         // this repository's sort and scan (bh_sort.hip.h); the rocPRIM ones above stay as the alternative path (NBODY_BH_HIPCUB)
         SortBuffers sort_main, sort_own;
         ScanState* scan_state = nullptr;
@@ -275,7 +276,7 @@ int enqueue_bh_build(nbody_ctx* ctx)
     const bool fused = n <= kBhSmallMax && b.gcap <= kBhSmallGhosts && !std::getenv("NBODY_BH_NO_FUSE");
     bh_keys_kernel<<<grid_n, blk, 0, s>>>(ctx->px, ctx->py, n, b.ctr, ctx->cfg.spread, adaptive ? 0 : 1, b.keys, b.vals, b.tie,
                                           b.gkeys, b.gvals, b.gcap, b.tie_table, b.tie_table_size, fused ? 1 : 0, ctx->m, b.body4);
-    const bool use_hipcub = std::getenv("NBODY_BH_HIPCUB") != nullptr;    // developer/test switch: rocPRIM's sort and scan
+    const bool use_hipcub = b.hipcub_ready && std::getenv("NBODY_BH_HIPCUB") != nullptr;    // developer/test switch: rocPRIM's sort and scan
     const char* rank_env = std::getenv("NBODY_BH_RANKSORT_MAX");         // developer/test switch
     // (the rank buffers exist only up to kBhRankSortMax bodies, nbody_create: the knob can lower the limit, never raise it)
     const int rank_max = rank_env ? (std::atoi(rank_env) < kBhRankSortMax ? std::atoi(rank_env) : kBhRankSortMax) : kBhRankSortMax;
@@ -363,7 +364,7 @@ int enqueue_bh_walk(nbody_ctx* ctx, int advance)
         auto& b = ctx->bh;
         if (b.own_order) {
             const int sb = ctx->cfg.shard_begin, sc = ctx->i_end - ctx->i_begin;
-            if (std::getenv("NBODY_BH_HIPCUB"))
+            if (b.hipcub_ready && std::getenv("NBODY_BH_HIPCUB"))
                 HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.own_sort_tmp, b.own_sort_bytes, b.keys + sb, b.own_keys_sorted, b.vals + sb,
                                                            b.own_order, sc, 0, 64, ctx->stream));
             else
@@ -463,7 +464,7 @@ ForcePlan make_force_plan(int n, int nt, int variant, int max_slices, int k_req 
 
 // the plan a context of this shape gets, developer knobs included (shared with nbody_accel_noalloc, whose results are
 // promised to be the context's bit for bit: same slices, same summation order)
-ForcePlan make_force_plan_env(int n, int nt, int variant, int fused_cap = 0)
+ForcePlan make_force_plan_env(int n, int nt, int variant)
 {
     // developer tuning knobs (not part of the ABI): NBODY_FORCE_K = 2|4, NBODY_FORCE_SLICES = 1..64,
     // NBODY_FORCE_TILE = small|big
@@ -477,7 +478,6 @@ ForcePlan make_force_plan_env(int n, int nt, int variant, int fused_cap = 0)
         if (v >= 1 && v <= kMaxSlices) want = v;
     }
     if (const char* e = std::getenv("NBODY_FORCE_TILE")) tile = (e[0] == 's') ? kTileSmall : big_tile_of(variant);
-    (void)fused_cap;
     return make_force_plan(n, nt, variant, kMaxSlices, k, want, tile);
 }
 
@@ -644,9 +644,15 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
         HIP_TRY_C(hipMalloc((void**)&b.grp_accepts, sizeof(int) * ((size_t)n / 8 + 1)));
         HIP_TRY_C(hipMemset(b.grp_visits, 0, sizeof(int) * ((size_t)n / 8 + 1)));
         HIP_TRY_C(hipMemset(b.grp_accepts, 0, sizeof(int) * ((size_t)n / 8 + 1)));
+        // rocPRIM's sort and scan: the alternative path of rounds 1-2, kept for A/B and cross-checks.  Its scratch (~24 B per
+        // body) is only allocated for a context created with NBODY_BH_HIPCUB set; without it the step path is this
+        // repository's kernels only and the switch is ignored.
+        b.hipcub_ready = std::getenv("NBODY_BH_HIPCUB") != nullptr;
+        if (b.hipcub_ready) {
         HIP_TRY_C(hipcub::DeviceRadixSort::SortPairs(nullptr, b.sort_bytes, b.keys, b.keys_sorted, b.vals, b.vals_sorted, n, 0, 64, ctx->stream));
         HIP_TRY_C(hipcub::DeviceRadixSort::SortPairs(nullptr, b.gsort_bytes, b.gkeys, b.gkeys_sorted, b.gvals, b.gvals_sorted, b.gcap, 0, 64, ctx->stream));
         HIP_TRY_C(hipcub::DeviceScan::ExclusiveSum(nullptr, b.scan_bytes, b.cnt, b.base, (int)nm, ctx->stream));
+        }
         // own sort / scan state: zeroed once, epochs start at 1 (no tag then equals a zero-initialised look-back word's)
         auto make_sort = [&](SortBuffers& sbuf, int count, uint64_t* tmp_k, int* tmp_v) -> hipError_t {
             hipError_t e = hipMalloc((void**)&sbuf.state, sizeof(SortState));
@@ -677,12 +683,16 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
             HIP_TRY_C(hipMalloc((void**)&b.own_keys_sorted, sizeof(uint64_t) * (size_t)sc));
             HIP_TRY_C(hipMalloc((void**)&b.own_order, sizeof(int) * (size_t)sc));
             HIP_TRY_C(make_sort(b.sort_own, sc, nullptr, nullptr));
-            HIP_TRY_C(hipcub::DeviceRadixSort::SortPairs(nullptr, b.own_sort_bytes, b.keys, b.own_keys_sorted, b.vals, b.own_order, sc, 0, 64, ctx->stream));
-            HIP_TRY_C(hipMalloc(&b.own_sort_tmp, b.own_sort_bytes ? b.own_sort_bytes : 16));
+            if (b.hipcub_ready) {
+                HIP_TRY_C(hipcub::DeviceRadixSort::SortPairs(nullptr, b.own_sort_bytes, b.keys, b.own_keys_sorted, b.vals, b.own_order, sc, 0, 64, ctx->stream));
+                HIP_TRY_C(hipMalloc(&b.own_sort_tmp, b.own_sort_bytes ? b.own_sort_bytes : 16));
+            }
         }
-        HIP_TRY_C(hipMalloc(&b.gsort_tmp, b.gsort_bytes ? b.gsort_bytes : 16));
-        HIP_TRY_C(hipMalloc(&b.sort_tmp, b.sort_bytes ? b.sort_bytes : 16));
-        HIP_TRY_C(hipMalloc(&b.scan_tmp, b.scan_bytes ? b.scan_bytes : 16));
+        if (b.hipcub_ready) {
+            HIP_TRY_C(hipMalloc(&b.gsort_tmp, b.gsort_bytes ? b.gsort_bytes : 16));
+            HIP_TRY_C(hipMalloc(&b.sort_tmp, b.sort_bytes ? b.sort_bytes : 16));
+            HIP_TRY_C(hipMalloc(&b.scan_tmp, b.scan_bytes ? b.scan_bytes : 16));
+        }
     }
 #undef HIP_TRY_C
     *out = ctx;

@@ -10,6 +10,7 @@ from nbody_amd import initial_conditions as ic
 sizes = [int(a) for a in sys.argv[1:]] or [20000, 65536, 262144, 1_000_000, 4_000_000]
 for n in sizes:
     b = ic.disc(n, seed=12345)
+    os.environ["NBODY_BH_HIPCUB"] = "1"                   # at creation: the context allocates rocPRIM's scratch too
     with nb.NBodySim(n, theta=1.0, useBarnesHut=True) as sim:
         sim.upload(*b)
         out = {}
