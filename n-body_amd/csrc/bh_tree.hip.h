@@ -1268,6 +1268,9 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     float4 a = w.A[0];
     int2 b = w.B[0];
     unsigned iters = 0;
+    // (Tried, round 3: a per-lane `while (active)` loop, finished groups masked off by the hardware instead of by the
+    // `if (active)` below.  It removes the ~10 register copies per iteration that the compiler makes around the divergent
+    // region, and is SLOWER: walk 2.07 against 1.99 ms at N = 10^6, 0.46 against 0.385 at 65 536 — same-box A/B.)
     while (__any(active)) {
         ++iters;
         if (active) {
