@@ -118,6 +118,9 @@ __device__ __forceinline__ f2 pair_weight(const f2 d2, const f2 ci, const Src<V>
 #ifndef NBODY_CLAMP_BLOCK
 #define NBODY_CLAMP_BLOCK 1
 #endif
+#ifndef NBODY_ASM_BROADCAST
+#define NBODY_ASM_BROADCAST 1    // 0: leave the source broadcast to the compiler (A/B: profiles/r3_asm_broadcast_ab.txt)
+#endif
 template <int G> __device__ __forceinline__ void clamp_square_block(const f2 (&inv)[G], f2 (&w)[G]);
 template <> __device__ __forceinline__ void clamp_square_block<4>(const f2 (&inv)[4], f2 (&w)[4])
 {
@@ -230,8 +233,18 @@ __global__ __launch_bounds__(kBlock, MINW) void force_naive_kernel(const ForceAr
                 s[u] = t[jj + u];              // wave-uniform address: LDS broadcast read
 #pragma unroll
                 for (int k = 0; k < KP; ++k) {
-                    dx[u * KP + k] = f2{s[u].x, s[u].x} - X[k];
-                    dy[u * KP + k] = f2{s[u].y, s[u].y} - Y[k];
+                    if constexpr (NBODY_ASM_BROADCAST && sizeof(S) == sizeof(f2)) {
+                        // {x,x} - X and {y,y} - Y with the broadcast in the instruction's op_sel bits.  hipcc finds that
+                        // form by itself for three of the four floats of a 16-byte LDS read and copies the fourth (the
+                        // odd source's y) with a v_mov_b32 first: 4 of 165 VALU instructions per 8 sources (round 3).
+                        f2 sv;
+                        __builtin_memcpy(&sv, &s[u], sizeof(f2));
+                        asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dx[u * KP + k]) : "v"(sv), "v"(X[k]));
+                        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dy[u * KP + k]) : "v"(sv), "v"(Y[k]));
+                    } else {
+                        dx[u * KP + k] = f2{s[u].x, s[u].x} - X[k];
+                        dy[u * KP + k] = f2{s[u].y, s[u].y} - Y[k];
+                    }
                 }
             }
 #pragma unroll
