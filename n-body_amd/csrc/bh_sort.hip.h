@@ -40,6 +40,10 @@ constexpr int kSortBlock = 256;             // 4 waves
 constexpr int kSortBins = 256;              // 8-bit digits
 constexpr int kSortDigits = 8;
 constexpr int kSortHistBlocks = 256;        // chunks of the histogram pass
+#ifndef NBODY_SORT_LOOK_W
+#define NBODY_SORT_LOOK_W 4
+#endif
+constexpr int kSortLookW = NBODY_SORT_LOOK_W;   // predecessor tiles a look-back step has in flight
 constexpr int kSortSpinLimit = 1 << 21;     // polls (each >= 128 cycles of s_sleep) before a wait gives up
 constexpr unsigned long long kLookAgg = 1ull << 30, kLookPrefix = 2ull << 30, kLookCount = (1ull << 30) - 1;
 
@@ -257,12 +261,12 @@ __global__ __launch_bounds__(kSortBlock) void sort_pass_kernel(SortState* __rest
             int at = tile - 1, spins = 0;
             bool found = false;
             while (!found) {
-                unsigned long long w[4];
+                unsigned long long w[kSortLookW];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w[j] = at - j >= 0 ? sort_look_load(look + (size_t)(at - j) * kSortBins + tid) : 0ull;
+                for (int j = 0; j < kSortLookW; ++j) w[j] = at - j >= 0 ? sort_look_load(look + (size_t)(at - j) * kSortBins + tid) : 0ull;
                 int used = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < kSortLookW; ++j) {
                     // ready = written by THIS pass of THIS sort (tag) with one of the two flags set
                     if (found || used != j || at - j < 0 || (unsigned)(w[j] >> 32) != tag || !(w[j] & (kLookAgg | kLookPrefix))) continue;
                     excl += (unsigned)(w[j] & kLookCount);

@@ -374,7 +374,13 @@ __device__ __forceinline__ void bh_spawn_ties(float x, float y, float spread, un
             if (slot < T.gcap) {
                 T.gkeys[slot] = k; T.gvals[slot] = body; T.gfx[slot] = nfx; T.gfy[slot] = nfy; T.gld[slot] = 0;
                 T.glo[slot] = lo; T.ghi[slot] = hi; T.gpos[slot] = pos;
-                __threadfence();                                 // the record before its index becomes findable
+                // The record before its index becomes findable — for observers on this CU only (workgroup scope: a wait,
+                // no cache-wide operation).  Nobody else can need more: a reader only follows table entries below the
+                // instance count it took at the start of its round (bh_tie_fixpoint_body), and those records were written
+                // before a kernel boundary or before the workgroup barrier that ended the round.  (Rounds 1-2 had a
+                // device-scope __threadfence() here — an L2 write-back and invalidate per instance: 185 of the 232 us of
+                // bh_ties_kernel and most of the fixed-point kernel at N = 2^24, 4271 instances.)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 int hs = bh_tie_hash(pos, T.table_mask);
                 while (atomicCAS(&T.table[hs], -1, slot) != -1) hs = (hs + 1) & T.table_mask;
             } else {
@@ -390,22 +396,43 @@ __device__ __forceinline__ int bh_first_tie(uint16_t rec)
     return tx < ty ? tx : ty;                                    // kBhLevels when the primary's path has none
 }
 
+// Lowest level at which a primary with path key k can sit on a split line at all, from the key alone (round 3: replaces a
+// 2-byte gather through the sorted index for EVERY body — 1 GB of memory sectors at N = 2^24 — by arithmetic on the key
+// the thread has already loaded; the exact record is then read by the few bodies that pass).  A coordinate equal to the
+// midpoint of level t takes the lower child there (bit 0) and is from then on the upper bound of its cell: it compares
+// above every later midpoint (bit 1) until a midpoint ROUNDS onto it, which needs a cell no wider than an ulp of the
+// coordinate, i.e. level >= 24 for coordinates inside the root box (cell width 2 h / 2^l against ulp <= h / 2^23).  So a
+// tie at level t <= 22 shows in the key as a 0 at level t followed by 1s down to level 22: the only candidate is the 0
+// just above the trailing 1s of levels 0..22; levels 23..30 stay possible for everybody.
+__device__ __forceinline__ int bh_min_tie_level(uint64_t k)
+{
+    const uint64_t odd = 0xAAAAAAAAAAAAAAAAull;
+    // x bits of levels 22, 21, ... 0 at bits 0, 2, ... 44 of k >> 16 (y: k >> 17); bit 46 is key bit 62 (63): always 0
+    const int rx = __builtin_ctzll(~((k >> 16) | odd)) >> 1, ry = __builtin_ctzll(~((k >> 17) | odd)) >> 1;
+    const int r = rx > ry ? rx : ry;                              // the longer run of trailing 1s = the lower candidate
+    return r >= 23 ? 23 : 22 - r;
+}
+
 __device__ __forceinline__ void bh_ties_one(int i, int M, const uint64_t* __restrict__ keys, const int* __restrict__ vals,
                                             const float* __restrict__ px, const float* __restrict__ py,
                                             const uint16_t* __restrict__ tie, BhCounters* __restrict__ ctr, const BhTies& T)
 {
-    const int b = vals[i];
-    const int first = bh_first_tie(tie[b]);
-    if (first == kBhLevels) return;                              // no split line on the primary's path:
-                                                                 // all but a few hundred per million
     const uint64_t k = keys[i];
     const int lp = i > 0 ? bh_lcp_levels(keys[i - 1], k) : -1;
     const int ln = i + 1 < M ? bh_lcp_levels(k, keys[i + 1]) : -1;
     const int leaf_depth = 1 + (lp > ln ? lp : ln);              // 0 when the body is alone in the tree
-    T.pld[i] = leaf_depth;
-    bh_spawn_ties(px[b], py[b], ctr->root_half, 0u, 0u, 0, leaf_depth, b, first, keys, vals, M, T, ctr);
+    T.pld[i] = leaf_depth;                                       // every primary: the fixed point raises it from here
+    const float spread = ctr->root_half;
+    // (the ulp argument needs normal floats: a root box of denormal size takes the exact path for every body)
+    if (spread >= 1e-20f && bh_min_tie_level(k) >= leaf_depth) return;   // no split line above the leaf: nearly everybody
+    const int b = vals[i];
+    const int first = bh_first_tie(tie[b]);
+    if (first >= leaf_depth) return;
+    bh_spawn_ties(px[b], py[b], spread, 0u, 0u, 0, leaf_depth, b, first, keys, vals, M, T, ctr);
 }
 
+// (Tried, round 3: four primaries per thread — fewer, fatter waves.  Slower, 447 against 232 us at N = 2^24: the kernel is
+// not bound by the wave launch rate but by the latency of the few lanes that pass the filter.)
 __global__ __launch_bounds__(kBhBlock) void bh_ties_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
                                                            const float* __restrict__ px, const float* __restrict__ py,
                                                            const uint16_t* __restrict__ tie, BhCounters* __restrict__ ctr,
@@ -482,66 +509,83 @@ __global__ __launch_bounds__(kBhFixBlock) void bh_tie_fixpoint_kernel(const uint
     bh_tie_fixpoint_body(keys, vals, px, py, tie, ctr, T, ctr->valid);
 }
 
-// Large builds with a tie buffer of at most kBhSmallGhosts entries (up to 2^20 bodies): the fixed point AND the sort of the
-// second instances in one launch of one workgroup — bitonic in LDS over the G real instances, total order (key, body),
-// the rest of the buffer padded — instead of a device-wide sort of 4096 mostly-padding entries.
-constexpr int kBhSmallGhosts = 4096;                // second instances the LDS sort holds (= the tie buffer below 2^20 bodies)
+// Large builds: the fixed point AND the sort of the second instances in one launch of one workgroup, total order
+// (key, body), the rest of the buffer padded — instead of a device-wide sort of a mostly-padding buffer.  Bitonic network;
+// up to kBhLdsGhosts instances entirely in LDS (96 KB: one workgroup runs, the CU's 160 KB are its own).  More of them
+// (only above 2^21 bodies, and then only on inputs with many thousands of bodies exactly on split lines): chunks of
+// kBhLdsGhosts are sorted in LDS, and of every later merge step only the strides >= a chunk run over device memory (loads
+// bypass the L1), the rest again chunk by chunk in LDS.  The output arrays are allocated to the next power of two.
+constexpr int kBhSmallGhosts = 4096;                // tie buffer up to which the SMALL build (bh_prep_small_kernel) is used
+constexpr int kBhLdsGhosts = 8192;                  // second instances the LDS of bh_tie_fixpoint_sort_kernel holds
 __global__ __launch_bounds__(kBhFixBlock) void bh_tie_fixpoint_sort_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
                                                                            const float* __restrict__ px, const float* __restrict__ py,
                                                                            const uint16_t* __restrict__ tie, BhCounters* __restrict__ ctr,
-                                                                           BhTies T, uint64_t* __restrict__ gkeys_sorted,
-                                                                           int* __restrict__ gvals_sorted)
+                                                                           BhTies T, uint64_t* gkeys_sorted, int* gvals_sorted)
 {
-    __shared__ uint64_t sk[kBhSmallGhosts];
-    __shared__ int sv[kBhSmallGhosts];
+    __shared__ uint64_t sk[kBhLdsGhosts];
+    __shared__ int sv[kBhLdsGhosts];
     const int tid = threadIdx.x;
     bh_tie_fixpoint_body(keys, vals, px, py, tie, ctr, T, ctr->valid);
     __syncthreads();            // one workgroup = one CU = one L1: a barrier is all the ordering the phases need
     const int ghosts = __hip_atomic_load(&ctr->ghosts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int gmax = T.gcap < kBhSmallGhosts ? T.gcap : kBhSmallGhosts;
-    const int G = ghosts < gmax ? ghosts : gmax;
-    if (G > 0) {
-        int P = 2;
-        while (P < G) P <<= 1;
-        for (int e = tid; e < P; e += kBhFixBlock) { sk[e] = e < G ? T.gkeys[e] : ~0ull; sv[e] = e < G ? T.gvals[e] : -1; }
-        __syncthreads();
-        for (int k = 2; k <= P; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int p = tid; p < (P >> 1); p += kBhFixBlock) {
-                    const int lo = ((p & ~(j - 1)) << 1) | (p & (j - 1)), hi = lo | j;
-                    const uint64_t ka = sk[lo], kb = sk[hi];
-                    const int va = sv[lo], vb = sv[hi];
-                    const bool gt = ka > kb || (ka == kb && va > vb);          // total order (key, body)
-                    if (gt == ((lo & k) == 0)) { sk[lo] = kb; sk[hi] = ka; sv[lo] = vb; sv[hi] = va; }
-                }
-                __syncthreads();
-            }
-    }
-    for (int e = tid; e < T.gcap; e += kBhFixBlock) { gkeys_sorted[e] = e < G ? sk[e] : ~0ull; gvals_sorted[e] = e < G ? sv[e] : -1; }
-    if (ghosts <= kBhSmallGhosts || T.gcap <= kBhSmallGhosts) return;
-    // More second instances than the LDS holds (only with more than 2^20 bodies, and then only on inputs with thousands
-    // of bodies exactly on split lines): the same bitonic network over the output arrays in device memory, still one
-    // workgroup.  Slow (milliseconds) and rare; the arrays are allocated to the next power of two.  Loads bypass the L1.
-    const int GG = ghosts < T.gcap ? ghosts : T.gcap;
+    const int G = ghosts < T.gcap ? ghosts : T.gcap;
     int P = 2;
-    while (P < GG) P <<= 1;
-    __syncthreads();
-    for (int e = tid; e < P; e += kBhFixBlock) { gkeys_sorted[e] = e < GG ? T.gkeys[e] : ~0ull; gvals_sorted[e] = e < GG ? T.gvals[e] : -1; }
-    __syncthreads();
+    while (P < G) P <<= 1;
+    const int C = P < kBhLdsGhosts ? P : kBhLdsGhosts;          // chunk: what one LDS load holds
     unsigned long long* gk = reinterpret_cast<unsigned long long*>(gkeys_sorted);
-    for (int k = 2; k <= P; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int p = tid; p < (P >> 1); p += kBhFixBlock) {
+    // stages `j_from`, j_from / 2, ... 1 of merge step k on the chunk at c0, in LDS (directions by the GLOBAL index)
+    auto lds_stages = [&](int c0, int k, int j_from) {
+        for (int j = j_from; j > 0; j >>= 1) {
+            for (int p = tid; p < (C >> 1); p += kBhFixBlock) {
                 const int lo = ((p & ~(j - 1)) << 1) | (p & (j - 1)), hi = lo | j;
-                const uint64_t ka = __hip_atomic_load(gk + lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint64_t kb = __hip_atomic_load(gk + hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int va = __hip_atomic_load(gvals_sorted + lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int vb = __hip_atomic_load(gvals_sorted + hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool gt = ka > kb || (ka == kb && va > vb);
-                if (gt == ((lo & k) == 0)) { gkeys_sorted[lo] = kb; gkeys_sorted[hi] = ka; gvals_sorted[lo] = vb; gvals_sorted[hi] = va; }
+                const uint64_t ka = sk[lo], kb = sk[hi];
+                const int va = sv[lo], vb = sv[hi];
+                const bool gt = ka > kb || (ka == kb && va > vb);          // total order (key, body)
+                if (gt == (((c0 + lo) & k) == 0)) { sk[lo] = kb; sk[hi] = ka; sv[lo] = vb; sv[hi] = va; }
             }
             __syncthreads();
         }
+    };
+    if (G > 0) {
+        // every chunk: load the unsorted instances (padding behind them), all merge steps up to the chunk size, store
+        for (int c0 = 0; c0 < P; c0 += C) {
+            for (int e = tid; e < C; e += kBhFixBlock) { sk[e] = c0 + e < G ? T.gkeys[c0 + e] : ~0ull; sv[e] = c0 + e < G ? T.gvals[c0 + e] : -1; }
+            __syncthreads();
+            for (int k = 2; k <= C; k <<= 1) lds_stages(c0, k, k >> 1);
+            if (P > C)
+                for (int e = tid; e < C; e += kBhFixBlock) { gkeys_sorted[c0 + e] = sk[e]; gvals_sorted[c0 + e] = sv[e]; }
+            __syncthreads();
+        }
+        for (int k = 2 * C; k <= P; k <<= 1) {
+            for (int j = k >> 1; j >= C; j >>= 1) {             // strides that cross chunks: over device memory
+                for (int p = tid; p < (P >> 1); p += kBhFixBlock) {
+                    const int lo = ((p & ~(j - 1)) << 1) | (p & (j - 1)), hi = lo | j;
+                    const uint64_t ka = __hip_atomic_load(gk + lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint64_t kb = __hip_atomic_load(gk + hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int va = __hip_atomic_load(gvals_sorted + lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int vb = __hip_atomic_load(gvals_sorted + hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool gt = ka > kb || (ka == kb && va > vb);
+                    if (gt == ((lo & k) == 0)) { gkeys_sorted[lo] = kb; gkeys_sorted[hi] = ka; gvals_sorted[lo] = vb; gvals_sorted[hi] = va; }
+                }
+                __syncthreads();
+            }
+            for (int c0 = 0; c0 < P; c0 += C) {                 // the strides inside a chunk: in LDS
+                for (int e = tid; e < C; e += kBhFixBlock) {
+                    sk[e] = __hip_atomic_load(gk + c0 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sv[e] = __hip_atomic_load(gvals_sorted + c0 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                lds_stages(c0, k, C >> 1);
+                for (int e = tid; e < C; e += kBhFixBlock) { gkeys_sorted[c0 + e] = sk[e]; gvals_sorted[c0 + e] = sv[e]; }
+                __syncthreads();
+            }
+        }
+    }
+    if (G > 0 && P <= C) {                                      // sorted in one piece: still in LDS
+        for (int e = tid; e < T.gcap; e += kBhFixBlock) { gkeys_sorted[e] = e < G ? sk[e] : ~0ull; gvals_sorted[e] = e < G ? sv[e] : -1; }
+    } else {                                                    // (the padding of the last chunk already sorts behind the instances)
+        for (int e = (G > 0 ? P : 0) + tid; e < T.gcap; e += kBhFixBlock) { gkeys_sorted[e] = ~0ull; gvals_sorted[e] = -1; }
+    }
 }
 
 // merge sorted primaries [n] and sorted second instances [gcap] into one sorted array [n + gcap]
@@ -558,6 +602,7 @@ __device__ __forceinline__ void bh_merge_one(int t, const uint64_t* __restrict__
     } else if (t < n + gcap) {
         const int g = t - n;
         const uint64_t k = gkeys[g];
+        if (k == ~0ull) { okeys[t] = k; ovals[t] = gvals[g]; return; }   // padding behind the instances: stays where it is
         int lo = 0, hi = n;                                    // primaries with a key <= mine
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] <= k) lo = mid + 1; else hi = mid; }
         // Second instances with EQUAL keys (bodies sharing a finest cell that sit on the same split lines) arrive from
@@ -575,16 +620,43 @@ __device__ __forceinline__ void bh_merge_one(int t, const uint64_t* __restrict__
     }
 }
 
+// A workgroup merges kBhMergePer x 256 consecutive entries.  Its primaries are a sorted stretch: the number of second
+// instances before the first and before the last of them (two lanes search, once per workgroup) bracket everybody
+// else's, and with a few thousand instances among millions of primaries the bracket is almost always empty — the
+// 16-step binary search per primary of round 2 (246 us at N = 2^24) is gone.
+constexpr int kBhMergePer = 4;
 __global__ __launch_bounds__(kBhBlock) void bh_merge_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals, int n,
                                                             const uint64_t* __restrict__ gkeys, const int* __restrict__ gvals,
                                                             int gcap, uint64_t* __restrict__ okeys, int* __restrict__ ovals,
                                                             BhCounters* __restrict__ ctr)
 {
-    const int t = blockIdx.x * kBhBlock + threadIdx.x;
+    __shared__ int s_lo[2];
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * (kBhBlock * kBhMergePer);
     // valid INSTANCES of the merged array = valid primaries + second instances (their keys have bit 63 clear, the
     // padding and the out-of-box bodies have it set and sort behind them); nobody else in this launch reads ctr
-    if (t == 0) ctr->valid += ctr->ghosts < gcap ? ctr->ghosts : gcap;
-    bh_merge_one(t, keys, vals, n, gkeys, gvals, gcap, okeys, ovals);
+    if (t0 == 0 && tid == 0) ctr->valid += ctr->ghosts < gcap ? ctr->ghosts : gcap;
+    const int p1 = min(n, t0 + kBhBlock * kBhMergePer);         // primaries of this workgroup: [t0, p1)
+    if (tid < 2 && t0 < p1) {
+        const uint64_t k = keys[tid == 0 ? t0 : p1 - 1];
+        int lo = 0, hi = gcap;                                 // second instances with a smaller key
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (gkeys[mid] < k) lo = mid + 1; else hi = mid; }
+        s_lo[tid] = lo;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kBhMergePer; ++u) {
+        const int t = t0 + u * kBhBlock + tid;
+        if (t < n) {
+            const uint64_t k = keys[t];
+            int lo = s_lo[0], hi = s_lo[1];
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (gkeys[mid] < k) lo = mid + 1; else hi = mid; }
+            okeys[t + lo] = k;
+            ovals[t + lo] = vals[t];
+        } else {
+            bh_merge_one(t, keys, vals, n, gkeys, gvals, gcap, okeys, ovals);
+        }
+    }
 }
 
 // 3. internal cells owned by each sorted body --------------------------------------------------------------
@@ -1082,18 +1154,28 @@ __device__ __forceinline__ void bh_com_cell(const BhTree& t, int c)
     rec[0] = cx; rec[1] = cy; rec[2] = ms;
 }
 
-// One launch per depth, deepest first (trees of more than 2^21 bodies).  One thread per 4 cells (one 32-bit load of
-// their depth bytes): a quarter of the threads of a launch per pool slot, short serial tails.
+// One launch per depth, deepest first (trees of more than 2^21 bodies).  One thread per 4 W cells (W 32-bit loads of
+// their depth bytes, issued together).  Measured at N = 2^24 (12 M cells): a launch that finds nothing costs its waves
+// (8.2 us with W = 1, 4.5 with W = 4), a populated one its memory traffic — 3 M cells in 177 us, ~3.4 TB/s of 64-byte
+// child blocks read and 12-byte records written — and is SLOWER with fatter threads (W = 4: +8 % over all levels).
+// So the host uses W = 4 for the depths that hold few cells on any input (the top of the tree and cells narrower than
+// 800 / 2^24) and W = 1 between.
+template <int W>
 __global__ __launch_bounds__(kBhBlock) void bh_com_kernel(BhTree t, const BhCounters* __restrict__ ctr, int d)
 {
     const int I = ctr->internal;
-    const int c4 = (blockIdx.x * kBhBlock + threadIdx.x) * 4;
-    if (c4 >= I) return;
-    const unsigned x = *reinterpret_cast<const unsigned*>(t.depth + c4) ^ (0x01010101u * (unsigned)d);
-    if (((x - 0x01010101u) & ~x & 0x80808080u) == 0) return;    // no zero byte = no cell of depth d here
+    const int c0 = (blockIdx.x * kBhBlock + threadIdx.x) * 4 * W;
+    if (c0 >= I) return;
+    unsigned x[W];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (((x >> (8 * k)) & 0xFFu) == 0 && c4 + k < I) bh_com_cell(t, c4 + k);
+    for (int w = 0; w < W; ++w) x[w] = reinterpret_cast<const unsigned*>(t.depth + c0)[w] ^ (0x01010101u * (unsigned)d);   // (16 bytes of slack behind the array)
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        if (((x[w] - 0x01010101u) & ~x[w] & 0x80808080u) == 0) continue;    // no zero byte = no cell of depth d here
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (((x[w] >> (8 * k)) & 0xFFu) == 0 && c0 + 4 * w + k < I) bh_com_cell(t, c0 + 4 * w + k);
+    }
 }
 
 // All depths in ONE launch, no level barrier: a cell without internal children is evaluated at once; its thread then

@@ -55,6 +55,7 @@ struct Profiler {
 };
 
 constexpr int kMaxSlices = 64;
+constexpr int kBhComSparseTop = 8, kBhComSparseBottom = 24;   // per-depth centre-of-mass launches: depths with few cells (bh_com_kernel)
 constexpr int kBhClimbMax = 1 << 21;         // bodies: up to here the centre-of-mass pass is ONE launch (bh_com_climb_kernel)
 constexpr float kBhSortedThetaScale = 0.6f;     // tools/bh_sorted_scale.py, profiles/r2_bh_sorted_scale.txt
 constexpr int kBhQuadMaxGroups = 6144;      // four waves per group (bh_walk_quad_kernel) up to 49 152 targets at theta >= 1 ...
@@ -310,11 +311,11 @@ int enqueue_bh_build(nbody_ctx* ctx)
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.gsort_tmp, b.gsort_bytes, b.gkeys, b.gkeys_sorted, b.gvals, b.gvals_sorted,
                                                        b.gcap, 0, 64, s));
         } else {
-            // the fixed point and the sort of the few second instances in one launch (in LDS up to 4096 of them)
+            // the fixed point and the sort of the few second instances in one launch (in LDS, 8192 at a time)
             bh_tie_fixpoint_sort_kernel<<<1, kBhFixBlock, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties,
                                                                   b.gkeys_sorted, b.gvals_sorted);
         }
-        bh_merge_kernel<<<grid_m, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, n, b.gkeys_sorted, b.gvals_sorted, b.gcap,
+        bh_merge_kernel<<<dim3((nm + kBhBlock * kBhMergePer - 1) / (kBhBlock * kBhMergePer)), blk, 0, s>>>(b.keys_sorted, b.vals_sorted, n, b.gkeys_sorted, b.gvals_sorted, b.gcap,
                                                b.keys_merged, b.vals_merged, b.ctr);
         if (use_hipcub) {
             bh_count_kernel<<<grid_m, blk, 0, s>>>(b.keys_merged, nm, b.ctr, b.cnt);
@@ -340,9 +341,12 @@ int enqueue_bh_build(nbody_ctx* ctx)
     if (n <= climb_max) {
         bh_com_climb_kernel<<<grid_c, blk, 0, s>>>(b.tree, b.ctr, std::getenv("NBODY_BH_CLIMB_SCATTER") ? 1 : 0);
     } else {
-        const dim3 grid_com((unsigned)((b.tree.cap_internal + 4 * kBhBlock - 1) / (4 * kBhBlock)));
-        for (int d = kBhLevels - 1; d >= 0; --d)
-            bh_com_kernel<<<grid_com, blk, 0, s>>>(b.tree, b.ctr, d);
+        const dim3 grid1((unsigned)((b.tree.cap_internal + 4 * kBhBlock - 1) / (4 * kBhBlock)));
+        const dim3 grid4((unsigned)((b.tree.cap_internal + 16 * kBhBlock - 1) / (16 * kBhBlock)));
+        for (int d = kBhLevels - 1; d >= 0; --d) {
+            if (d <= kBhComSparseTop || d >= kBhComSparseBottom) bh_com_kernel<4><<<grid4, blk, 0, s>>>(b.tree, b.ctr, d);
+            else                                                  bh_com_kernel<1><<<grid1, blk, 0, s>>>(b.tree, b.ctr, d);
+        }
     }
     HIP_TRY(hipGetLastError());
     return profile_end(ctx, 2, ep);

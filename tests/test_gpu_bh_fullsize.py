@@ -80,17 +80,19 @@ def test_plummer_4m_tree_and_sampled_walk_equal_the_oracle(nb, O):
     assert np.array_equal(ax[:nt], ox[:nt].astype(np.float32)) and np.array_equal(ay[:nt], oy[:nt].astype(np.float32))
 
 
-def test_more_split_line_bodies_than_the_lds_sort_holds(nb, O):
-    """2^21 bodies of which 6000 sit exactly on the root's vertical split line (x = 0): more second instances than
-    bh_tie_fixpoint_sort_kernel sorts in LDS (4096), so its device-memory network runs.  The tree (every node), the
-    counters and the accelerations of the first 4096 targets equal the build with rocPRIM's sort and scan
-    (NBODY_BH_HIPCUB) bit for bit; node count and root record equal the oracle's serially inserted tree."""
+@pytest.mark.parametrize("n,on_line", [(1 << 21, 6000), (1 << 22, 10000)])
+def test_more_split_line_bodies_than_the_lds_sort_holds(nb, O, n, on_line):
+    """2^21 (2^22) bodies of which 6000 (10 000) sit exactly on the root's vertical split line (x = 0): more second
+    instances than the small build's LDS sort holds (4096) and, in the second case, than ONE LDS load of
+    bh_tie_fixpoint_sort_kernel (8192), so that its chunked network with strides over device memory runs.  The tree
+    (every node), the counters and the accelerations of the first 4096 targets equal the build with rocPRIM's sort and
+    scan (NBODY_BH_HIPCUB) bit for bit; node count and root record equal the oracle's serially inserted tree."""
     import ctypes as C
     import os
-    n, nt = 1 << 21, 4096
+    nt = 4096
     b = O.init_disc(n, seed=99)
     rng = np.random.default_rng(5)
-    on = rng.choice(n, size=6000, replace=False)
+    on = rng.choice(n, size=on_line, replace=False)
     b.posX[on] = 0.0
     b.posY[on] = np.linspace(-399.0, 399.0, len(on)).astype(np.float32)      # distinct: coincident bodies recurse without end
     got = {}                                                                 # in the reference (and in the oracle that follows it)
@@ -114,4 +116,4 @@ def test_more_split_line_bodies_than_the_lds_sort_holds(nb, O):
     oroot = np.frombuffer((C.c_char * 48).from_address(O.lib().oracle_tree_pool(ot.h)), dtype=O.NODE_DTYPE)[0]
     for f in ("mass", "comX", "comY"):
         assert tree[0][f] == oroot[f], f
-    assert float(tree[0]["mass"]) > 1000.0 * (n + 5900)          # the 6000 are in the tree twice (benchmark.cpp:83-85)
+    assert float(tree[0]["mass"]) > 1000.0 * (n + on_line - 100)  # the bodies on the line are in the tree twice (benchmark.cpp:83-85)
