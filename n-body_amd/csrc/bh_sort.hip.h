@@ -338,8 +338,10 @@ constexpr int kSortShortRun = 32;
 constexpr int kSortQueueCap = 1 << 16;
 constexpr int kSortLongBlocks = 64;
 
+// low63: if not null, receives the number of keys with bit 63 clear (= where they end in the sorted order: the caller's
+// "valid" count, one 1-thread launch less in the Barnes-Hut build).
 __global__ __launch_bounds__(kSortBlock) void sort_fix_runs_kernel(uint64_t* keys, int* vals, int n, SortState* __restrict__ st,
-                                                                  int* __restrict__ queue)
+                                                                  int* __restrict__ queue, int* __restrict__ low63)
 {
     const int i = blockIdx.x * kSortBlock + threadIdx.x;
     if (i >= n) return;
@@ -347,7 +349,13 @@ __global__ __launch_bounds__(kSortBlock) void sort_fix_runs_kernel(uint64_t* key
     const uint64_t p = keys[i] >> sh;
     // (a neighbour's key may be mid-move by the thread that sorts its run: the bits above `sh` are the same in every
     // pair of a run and an 8-byte store is one instruction, so what is read here is right either way)
-    if (i > 0 && (keys[i - 1] >> sh) == p) return;              // not the head of a run
+    const uint64_t before = i > 0 ? keys[i - 1] >> sh : 0;
+    if (low63) {                                                // exactly one thread sees the boundary
+        const bool hi_here = (p >> (63 - sh)) != 0, hi_before = i > 0 && (before >> (63 - sh)) != 0;
+        if (hi_here && !hi_before) *low63 = i;
+        if (i == n - 1 && !hi_here) *low63 = n;
+    }
+    if (i > 0 && before == p) return;                           // not the head of a run
     if (i + 1 >= n || (keys[i + 1] >> sh) != p) return;         // a run of one: nearly everybody
     int len = 2;
     while (i + len < n && len <= kSortShortRun && (keys[i + len] >> sh) == p) ++len;
@@ -462,10 +470,11 @@ inline int sort_tiles(int n) { const int t = kSortBlock * sort_per_thread(n); re
 inline size_t sort_hist_part_bytes() { return sizeof(unsigned) * (size_t)kSortHistBlocks * kSortDigits * kSortBins; }
 
 // Enqueue the sort: 10 launches, or 9 when `truncated` (5 sweeps + the two run kernels).  tmp_k/tmp_v: n entries each.
-inline void sort_pairs(const SortBuffers& sb, const uint64_t* in_k, const int* in_v, uint64_t* out_k, int* out_v, int n, hipStream_t s,
-                       bool truncated = false)
+// Returns true when *low63 has been (will have been) written: only the truncated sort has the kernel that does it.
+inline bool sort_pairs(const SortBuffers& sb, const uint64_t* in_k, const int* in_v, uint64_t* out_k, int* out_v, int n, hipStream_t s,
+                       bool truncated = false, int* low63 = nullptr)
 {
-    if (n <= 0) return;
+    if (n <= 0) return false;
     if (std::getenv("NBODY_SORT_FULL")) truncated = false;                                      // developer/test switch
     const int first = truncated ? kSortLowDigits : 0;
     const int tiles = sort_tiles(n);
@@ -480,9 +489,10 @@ inline void sort_pairs(const SortBuffers& sb, const uint64_t* in_k, const int* i
             sort_pass_kernel<8><<<dim3(tiles), dim3(kSortBlock), 0, s>>>(sb.state, k, n, in_k, in_v, out_k, out_v, sb.tmp_k, sb.tmp_v, sb.look);
     }
     if (truncated) {
-        sort_fix_runs_kernel<<<dim3((n + kSortBlock - 1) / kSortBlock), dim3(kSortBlock), 0, s>>>(out_k, out_v, n, sb.state, sb.queue);
+        sort_fix_runs_kernel<<<dim3((n + kSortBlock - 1) / kSortBlock), dim3(kSortBlock), 0, s>>>(out_k, out_v, n, sb.state, sb.queue, low63);
         sort_long_runs_kernel<<<dim3(kSortLongBlocks), dim3(kSortBlock), 0, s>>>(out_k, out_v, sb.tmp_k, sb.tmp_v, n, sb.state, sb.queue);
     }
+    return truncated && low63 != nullptr;
 }
 
 }  // namespace nbody

@@ -686,11 +686,13 @@ __device__ __forceinline__ int bh_lower_bound(const uint64_t* __restrict__ keys,
     return lo;
 }
 
-// first index in [lo, hi) whose key is >= v, galloping from lo (the answer is usually a few bodies away)
+// first index in [lo, hi) whose key is >= v, galloping from lo (the answer is usually a few bodies away).  The stride
+// doubles up to 16 and then grows fourfold: a far answer (the end of a cell near the root) is bracketed in half the
+// steps, for two more steps of the binary search that follows.
 __device__ __forceinline__ int bh_gallop_lower_bound(const uint64_t* __restrict__ keys, int lo, int hi, uint64_t v)
 {
     int a = lo, step = 1;
-    while (a + step <= hi && keys[a + step - 1] < v) { a += step; step <<= 1; }
+    while (a + step <= hi && keys[a + step - 1] < v) { a += step; step <<= (step >= 16 ? 2 : 1); }
     const int e = a + step < hi ? a + step : hi;
     return bh_lower_bound(keys, a, e, v);
 }
@@ -984,6 +986,7 @@ __global__ __launch_bounds__(kBhFixBlock) void bh_prep_small_kernel(const uint64
     BH_DBG_TICK(ctr, 6);
 }
 
+constexpr int kBhNodesSmallSpan = 64;         // instances up to which a cell's quadrant boundaries are found by galloping
 struct BhWaitErrors { const int* p[3]; };      // SortState::error / ScanState::error of the kernels before (nullptr: not used)
 
 // 4b. one thread per internal cell: box, body range (galloping from the owner: the range of a typical cell is a
@@ -1051,8 +1054,28 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
     int s[5];
     s[0] = i;
     s[4] = e;
+    if (e - i <= kBhNodesSmallSpan) {
 #pragma unroll
-    for (int q = 1; q < 4; ++q) s[q] = bh_gallop_lower_bound(keys, s[q - 1], e, ((prefix << 2) | (uint64_t)q) << cshift);
+        for (int q = 1; q < 4; ++q) s[q] = bh_gallop_lower_bound(keys, s[q - 1], e, ((prefix << 2) | (uint64_t)q) << cshift);
+    } else {
+        // A cell near the root spans 10^4-10^6 instances; three galloping searches, each starting where the one before
+        // ended, are ~100 dependent loads there, and at N = 10^6 — one wave per SIMD — those few lanes ARE the kernel's
+        // duration.  Three binary searches over [i, e) side by side: their loads are independent, the chain is log2(span).
+        int lo[4], hi[4];
+        uint64_t v[4];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) { lo[q] = i; hi[q] = e; v[q] = ((prefix << 2) | (uint64_t)q) << cshift; }
+        while (lo[1] < hi[1] || lo[2] < hi[2] || lo[3] < hi[3]) {
+            uint64_t km[4];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) km[q] = lo[q] < hi[q] ? keys[(lo[q] + hi[q]) >> 1] : 0;
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (lo[q] < hi[q]) { const int mid = (lo[q] + hi[q]) >> 1; if (km[q] < v[q]) lo[q] = mid + 1; else hi[q] = mid; }
+        }
+#pragma unroll
+        for (int q = 1; q < 4; ++q) s[q] = lo[q];
+    }
 
     const float mx = (tlx + brx) / 2.0f;
     int internal_children = 0;

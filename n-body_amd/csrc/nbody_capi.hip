@@ -282,6 +282,7 @@ int enqueue_bh_build(nbody_ctx* ctx)
     // (the rank buffers exist only up to kBhRankSortMax bodies, nbody_create: the knob can lower the limit, never raise it)
     const int rank_max = rank_env ? (std::atoi(rank_env) < kBhRankSortMax ? std::atoi(rank_env) : kBhRankSortMax) : kBhRankSortMax;
     const bool ranked = fused && b.rank != nullptr && n <= rank_max;
+    bool valid_counted = false;
     if (ranked) {
         // small N: rank by brute-force counting, one launch.  ~1024 workgroups: i-tiles of 256 x j-slices
         const int tiles = (int)grid_n.x;
@@ -294,7 +295,9 @@ int enqueue_bh_build(nbody_ctx* ctx)
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, b.keys, b.keys_sorted, b.vals, b.vals_sorted, n,
                                                    0, 64, s));
     } else {
-        sort_pairs(b.sort_main, b.keys, b.vals, b.keys_sorted, b.vals_sorted, n, s, true);    // TMP = the merged arrays, written later
+        // TMP = the merged arrays, written later.  The sort's run kernel also leaves the number of in-box bodies (keys with
+        // bit 63 clear) in ctr->valid; bh_keys_kernel has reset it to 0, which stands when there are none.
+        valid_counted = sort_pairs(b.sort_main, b.keys, b.vals, b.keys_sorted, b.vals_sorted, n, s, true, fused ? nullptr : &b.ctr->valid);
     }
     // bodies exactly on a split line get a second instance (inclusive bounds, benchmark.cpp:83-85)
     BhTies ties{b.gkeys, b.gvals, b.gfx, b.gfy, b.gld, b.glo, b.ghi, b.gpos, b.pld, b.tie_table, b.tie_table_size - 1, b.gcap};
@@ -304,7 +307,7 @@ int enqueue_bh_build(nbody_ctx* ctx)
                                                        b.gkeys_sorted, b.gvals_sorted, b.keys_merged, b.vals_merged, b.cnt, b.base,
                                                        b.owner, b.tree.cap_internal, ranked ? b.tie_first_sorted : nullptr);
     } else {
-        bh_valid_kernel<<<1, 64, 0, s>>>(b.keys_sorted, n, b.ctr);
+        if (!valid_counted) bh_valid_kernel<<<1, 64, 0, s>>>(b.keys_sorted, n, b.ctr);
         bh_ties_kernel<<<grid_n, blk, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties);
         if (use_hipcub) {
             bh_tie_fixpoint_kernel<<<1, kBhFixBlock, 0, s>>>(b.keys_sorted, b.vals_sorted, ctx->px, ctx->py, b.tie, b.ctr, ties);
