@@ -27,8 +27,9 @@
 //                         + 2 v_pk_fma (accumulate)  = 8 packed + 2 transcendental = 48 issue cycles,
 // i.e. 24 cycles per interaction per wave64 against 20 at the "20 flop = 100 %" convention: the
 // instruction mix itself caps this kernel at 83 % of the 157.3 TFLOP/s headline, which assumes 2.4 GHz; at the
-// 2.25-2.34 GHz the chip holds under this load at its ~1.4 kW power cap that is 78-81 %.  Measured 0.75-0.78
-// (179.5-186.6 ms per N = 2^20 launch; the spread between boxes is the clock, see bench.py's `clock` field).
+// 2.23-2.34 GHz the chip holds under this load at its ~1.4 kW power cap that is 77-81 %.  Measured 0.756-0.789
+// (177.2-185.0 ms per N = 2^20 launch at the end of round 3, 0.81 of the peak at the measured clock on every box; the
+// spread between boxes is the clock, see bench.py's `clock` field).
 #pragma once
 #include <hip/hip_runtime.h>
 
