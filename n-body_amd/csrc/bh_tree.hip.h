@@ -380,7 +380,11 @@ __device__ __forceinline__ void bh_spawn_ties(float x, float y, float spread, un
                 // before a kernel boundary or before the workgroup barrier that ended the round.  (Rounds 1-2 had a
                 // device-scope __threadfence() here — an L2 write-back and invalidate per instance: 185 of the 232 us of
                 // bh_ties_kernel and most of the fixed-point kernel at N = 2^24, 4271 instances.)
+#ifdef NBODY_SPAWN_FENCE_DEVICE
+                __threadfence();
+#else
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#endif
                 int hs = bh_tie_hash(pos, T.table_mask);
                 while (atomicCAS(&T.table[hs], -1, slot) != -1) hs = (hs + 1) & T.table_mask;
             } else {
@@ -409,8 +413,9 @@ __device__ __forceinline__ int bh_min_tie_level(uint64_t k)
     const uint64_t odd = 0xAAAAAAAAAAAAAAAAull;
     // x bits of levels 22, 21, ... 0 at bits 0, 2, ... 44 of k >> 16 (y: k >> 17); bit 46 is key bit 62 (63): always 0
     const int rx = __builtin_ctzll(~((k >> 16) | odd)) >> 1, ry = __builtin_ctzll(~((k >> 17) | odd)) >> 1;
-    const int r = rx > ry ? rx : ry;                              // the longer run of trailing 1s = the lower candidate
-    return r >= 23 ? 23 : 22 - r;
+    // (an axis whose 23 bits are all 1 — a coordinate on the box's upper edge — has no candidate up here: per axis, then min)
+    const int tx = rx >= 23 ? 23 : 22 - rx, ty = ry >= 23 ? 23 : 22 - ry;
+    return tx < ty ? tx : ty;
 }
 
 __device__ __forceinline__ void bh_ties_one(int i, int M, const uint64_t* __restrict__ keys, const int* __restrict__ vals,
@@ -424,7 +429,10 @@ __device__ __forceinline__ void bh_ties_one(int i, int M, const uint64_t* __rest
     T.pld[i] = leaf_depth;                                       // every primary: the fixed point raises it from here
     const float spread = ctr->root_half;
     // (the ulp argument needs normal floats: a root box of denormal size takes the exact path for every body)
-    if (spread >= 1e-20f && bh_min_tie_level(k) >= leaf_depth) return;   // no split line above the leaf: nearly everybody
+#ifndef NBODY_TIES_KEY_FILTER
+#define NBODY_TIES_KEY_FILTER 1
+#endif
+    if (NBODY_TIES_KEY_FILTER && spread >= 1e-20f && bh_min_tie_level(k) >= leaf_depth) return;   // no split line above the leaf: nearly everybody
     const int b = vals[i];
     const int first = bh_first_tie(tie[b]);
     if (first >= leaf_depth) return;

@@ -44,17 +44,15 @@ def make(kind, n, rng):
     return b
 
 
-def main():
-    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-    rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+def stress(seed, rounds, fast=False, adaptive=False, max_n=20000):
+    """fast: bh_fast_math (same node count and counters required, accelerations to 1e-4); adaptive: adaptive_box (the
+    oracle gets the bounding half-width as its `spread`).  Returns the number of failed rounds."""
     rng = np.random.default_rng(seed)
-    fast = "--fast" in sys.argv          # bh_fast_math: same node count and counters required, accelerations to 1e-4
-    adaptive = "--adaptive" in sys.argv  # adaptive_box: the oracle gets the bounding half-width as its `spread`
     bad = 0
     t0 = time.time()
     for r in range(rounds):
         kind = ["lattice", "cluster", "wide", "axis", "disc"][r % 5]
-        n = int(rng.choice([1, 2, 7, 8, 9, 63, 100, 1000, 4097, 20000]))
+        n = min(max_n, int(rng.choice([1, 2, 7, 8, 9, 63, 100, 1000, 4097, 20000])))
         if kind in ("lattice", "axis", "cluster"): n = min(n, 4097)   # stay inside the tie buffer (4096 second instances)
         theta = float(rng.choice([1.0, 0.5, 0.3, 1.5]))
         b = make(kind, n, rng)
@@ -95,7 +93,13 @@ def main():
         if status != "ok": bad += 1
         print(f"[{r:3d}] {kind:8s} n={n:6d} theta={theta:3.1f}: {status}", flush=True)
     print(f"{rounds - bad}/{rounds} ok in {time.time() - t0:.1f}s", flush=True)
-    sys.exit(1 if bad else 0)
+    return bad
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    sys.exit(1 if stress(seed, rounds, fast="--fast" in sys.argv, adaptive="--adaptive" in sys.argv) else 0)
 
 
 if __name__ == "__main__":
