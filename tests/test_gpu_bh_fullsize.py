@@ -117,3 +117,50 @@ def test_more_split_line_bodies_than_the_lds_sort_holds(nb, O, n, on_line):
     for f in ("mass", "comX", "comY"):
         assert tree[0][f] == oroot[f], f
     assert float(tree[0]["mass"]) > 1000.0 * (n + on_line - 100)  # the bodies on the line are in the tree twice (benchmark.cpp:83-85)
+
+
+@pytest.mark.parametrize("n,spread_mode", [(300_000, "fixed"), (300_000, "adaptive"), (3_000_000, "fixed")])
+def test_lattice_points_in_a_large_disc_equal_the_oracle(nb, O, n, spread_mode):
+    """The LARGE build's split-line path (bh_ties_kernel with its key-based filter, the fixed-point kernel, the bracketed
+    merge; at 3 x 10^6 bodies also the per-depth centre-of-mass launches) on an input made for it: a seeded disc in which
+    3000 bodies are moved onto a 2^-k lattice — every one of them on split lines at some level above its leaf — a tenth
+    of those onto the box's own edges and axes (x or y = +-400 or 0).  Node count, root record, and the accelerations and
+    counters of the first 4096 targets equal the oracle's, bit for bit.  (tools/bh_stress.py runs lattices through the
+    small build only: they fill the tie buffer at its sizes.)"""
+    import ctypes as C
+    nt = 4096
+    b = O.init_disc(n, seed=4242)
+    rng = np.random.default_rng(n)
+    on = rng.choice(n, size=3000, replace=False)
+    k = 9
+    step = 400.0 / (1 << k)
+    gx = rng.integers(-(1 << k), (1 << k) + 1, len(on)); gy = rng.integers(-(1 << k), (1 << k) + 1, len(on))
+    edge = rng.random(len(on)) < 0.1
+    gx = np.where(edge & (rng.random(len(on)) < 0.5), rng.choice([-(1 << k), 0, 1 << k], len(on)), gx)
+    gy = np.where(edge & (rng.random(len(on)) < 0.5), rng.choice([-(1 << k), 0, 1 << k], len(on)), gy)
+    # distinct positions (coincident bodies recurse without end in the reference): keep the first body of every lattice site
+    _, first = np.unique(gx * 4096 + gy, return_index=True)
+    on, gx, gy = on[first], gx[first], gy[first]
+    b.posX[on] = (gx * step).astype(np.float32)
+    b.posY[on] = (gy * step).astype(np.float32)
+    half = rng.random(len(on)) < 0.5                                     # half of them leave the lattice in x (still on a y line)
+    b.posX[on] = np.where(half, b.posX[on] + np.float32(0.37 * step) * (np.abs(b.posX[on]) < 399), b.posX[on]).astype(np.float32)
+    adaptive = spread_mode == "adaptive"
+    box = float(max(np.abs(b.posX).max(), np.abs(b.posY).max())) if adaptive else 400.0
+    with nb.NBodySim(n, theta=1.0, useBarnesHut=True, shard=(0, nt), adaptive_box=adaptive) as sim:
+        sim.upload(*b.arrays())
+        sim.compute_accel().sync()
+        ax, ay = sim.accel()
+        root = sim.bh_tree(max_nodes=1)[0]
+        total = sim.bh_nodes_total
+        cnt = sim.bh_counters()
+    ot = O.Tree(n).build(b, box)
+    assert total == ot.nodes_used
+    oroot = np.frombuffer((C.c_char * 48).from_address(O.lib().oracle_tree_pool(ot.h)), dtype=O.NODE_DTYPE)[0]
+    for f in ("mass", "comX", "comY"):
+        assert root[f] == oroot[f], f
+    assert float(root["mass"]) > 1000.0 * (n + 0.9 * len(on))            # the lattice bodies are in the tree at least twice
+    ox = np.zeros(n); oy = np.zeros(n); oc = np.zeros(2, np.int64)
+    O.lib().oracle_bh_accel(ot.h, nt, b.posX, b.posY, b.radius, 1.0, 0, 8, ox, oy, oc)
+    assert cnt == dict(visits=int(oc[0]), accepts=int(oc[1]))
+    assert np.array_equal(ax[:nt], ox[:nt].astype(np.float32)) and np.array_equal(ay[:nt], oy[:nt].astype(np.float32))
