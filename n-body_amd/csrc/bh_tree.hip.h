@@ -994,6 +994,9 @@ __global__ __launch_bounds__(kBhFixBlock) void bh_prep_small_kernel(const uint64
     BH_DBG_TICK(ctr, 6);
 }
 
+#ifndef NBODY_NODES_LDS_STORES
+#define NBODY_NODES_LDS_STORES 1
+#endif
 constexpr int kBhNodesSmallSpan = 64;         // instances up to which a cell's quadrant boundaries are found by galloping
 struct BhWaitErrors { const int* p[3]; };      // SortState::error / ScanState::error of the kernels before (nullptr: not used)
 
@@ -1032,8 +1035,21 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
             t.B[0] = make_int2(-1, b);
         }
     }
-    if (c >= I || c >= t.cap_internal) return;
-
+    const int limit = I < t.cap_internal ? I : t.cap_internal;
+#if NBODY_NODES_LDS_STORES
+    // The four child records of a cell are 64 + 32 contiguous bytes, but a lane that stores its own cell's writes 16
+    // (8) bytes at a stride of 64 (32): every store instruction touches 64 lines partially.  Staged through LDS, a
+    // wave's 64 cells go out as 4 + 4 fully coalesced stores.
+    __shared__ float4 sA[kBhBlock / 64][256];
+    __shared__ int2 sB[kBhBlock / 64][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c_wave0 = c - lane;
+    if (c_wave0 >= limit) return;                              // wave-uniform
+    if (c < limit) {
+#else
+    if (c >= limit) return;
+    {
+#endif
     const int i = owner[c];
     const uint64_t ki = keys[i];
     const int lp = i > 0 ? bh_lcp_levels(keys[i - 1], ki) : -1;
@@ -1130,10 +1146,28 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
             cm = ms;
             if (ms > 0.0f) { cx = sx / ms; cy = sy / ms; }
         }
+#if NBODY_NODES_LDS_STORES
+        sA[wv][4 * lane + q] = make_float4(cx, cy, cm, width);
+        sB[wv][4 * lane + q] = make_int2(child_base, body);
+#else
         t.A[node] = make_float4(cx, cy, cm, width);
         t.B[node] = make_int2(child_base, body);
+#endif
     }
     t.pend[c] = internal_children ? internal_children : -1;
+    }
+#if NBODY_NODES_LDS_STORES
+    // (one wave, its own LDS rows: LDS executes a wave's instructions in order; the fences are for the compiler)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int records = 4 * (limit - c_wave0 < 64 ? limit - c_wave0 : 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int idx = r * 64 + lane;
+        if (idx < records) { t.A[1 + 4 * c_wave0 + idx] = sA[wv][idx]; t.B[1 + 4 * c_wave0 + idx] = sB[wv][idx]; }
+    }
+#endif
 }
 
 // Read-back only (nbody_bh_tree_nodes): the box {tlX, tlY, brX, brY} of every node, recomputed from the topology —
