@@ -13,7 +13,7 @@
 //      sort_pass_kernel   one launch per digit position.  Dead positions are skipped ON THE DEVICE (the launch sequence is
 //                         static, so that it can sit in a hipGraph): from the live mask every workgroup knows which buffer
 //                         this pass reads and which it writes, such that the LAST live pass lands in the output arrays.
-//                         A live pass is one sweep: a workgroup takes the next tile (ticket), ranks its 256 x E pairs
+//                         A live pass is one sweep: a workgroup takes the next tile (ticket), ranks its 2048 or 4096 pairs
 //                         stably in LDS (per wave: 8 ballots give every lane the peers that share its digit; per-wave
 //                         counters; a 256-bin scan), publishes the tile's bin counts, collects the counts of all tiles
 //                         before it (below) and scatters through LDS in runs of equal digits.
@@ -38,6 +38,9 @@ namespace nbody {
 
 constexpr int kSortBlock = 256;             // 4 waves
 constexpr int kSortBins = 256;              // 8-bit digits
+constexpr int kSortPassBlock = 512;         // threads of a sort_pass_kernel workgroup (256, 512 or 1024: the tile stays the same).
+                                            // Measured per sweep, 256 / 512 / 1024 threads: N = 2 x 10^5 13.0 / 11.8 / 12.0 us, 10^6 22.7 /
+                                            // 20.3 / 20.2, 4 x 10^6 49.8 / 45.3 / 53.2, 2^24 167 / 155 / 197 (8192-pair tiles at 512: +-0)
 constexpr int kSortDigits = 8;
 constexpr int kSortHistBlocks = 256;        // chunks of the histogram pass
 #ifndef NBODY_SORT_LOOK_W
@@ -77,7 +80,8 @@ __device__ __forceinline__ void sort_look_store(unsigned long long* p, unsigned 
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// exclusive scan of one value per thread over a 256-thread workgroup; `part` is 4 words of LDS.  Ends with a barrier.
+// exclusive scan of one value per thread over a BLOCK-thread workgroup; `part` is BLOCK / 64 words of LDS.  Ends with a barrier.
+template <int BLOCK = kSortBlock>
 __device__ __forceinline__ unsigned sort_block_excl_scan(unsigned v, unsigned* part)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -91,7 +95,7 @@ __device__ __forceinline__ unsigned sort_block_excl_scan(unsigned v, unsigned* p
     __syncthreads();
     unsigned before = 0;
 #pragma unroll
-    for (int w = 0; w < kSortBlock / 64; ++w) { const unsigned p = part[w]; if (w < wave) before += p; }
+    for (int w = 0; w < BLOCK / 64; ++w) { const unsigned p = part[w]; if (w < wave) before += p; }
     __syncthreads();
     return before + incl - v;
 }
@@ -161,21 +165,23 @@ __global__ __launch_bounds__(1024) void sort_plan_kernel(const unsigned* __restr
 
 inline size_t sort_look_words(int tiles) { return (size_t)tiles * kSortBins; }
 
-// One digit position.  E pairs per thread, tile = 256 * E.  Buffers: IN (read-only), OUT (final result), TMP.
-template <int E>
-__global__ __launch_bounds__(kSortBlock) void sort_pass_kernel(SortState* __restrict__ st, int k, int n,
+// One digit position.  BLOCK threads, E pairs per thread, tile = BLOCK * E.  Buffers: IN (read-only), OUT (final result), TMP.
+// The 256 bins belong to the first 256 threads; with more threads per workgroup the same tile has fewer serial ranking
+// rounds per wave and more loads in flight per CU.
+template <int E, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void sort_pass_kernel(SortState* __restrict__ st, int k, int n,
                                                               const uint64_t* __restrict__ in_k, const int* __restrict__ in_v,
                                                               uint64_t* __restrict__ out_k, int* __restrict__ out_v,
                                                               uint64_t* __restrict__ tmp_k, int* __restrict__ tmp_v,
                                                               unsigned long long* __restrict__ look)
 {
-    constexpr int T = kSortBlock * E;
-    __shared__ unsigned wave_hist[kSortBlock / 64][kSortBins];
+    constexpr int T = BLOCK * E;
+    __shared__ unsigned wave_hist[BLOCK / 64][kSortBins];
     __shared__ unsigned bin_start[kSortBins];
     __shared__ int gbase[kSortBins];
     __shared__ uint64_t skey[T];
     __shared__ int sval[T];
-    __shared__ unsigned part[kSortBlock / 64];
+    __shared__ unsigned part[BLOCK / 64];
     __shared__ int s_tile;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef NBODY_WIDE_TIMING
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_pass_kernel(SortState* __rest
     const int tile = work ? s_tile : 0;
     if (!work && k == kSortDigits - 1 && P == 0 && n > 0) {
         // nothing to sort (one element, or all keys equal): the output is the input
-        for (int i = (int)blockIdx.x * T + tid; i < min(n, ((int)blockIdx.x + 1) * T); i += kSortBlock) { out_k[i] = in_k[i]; out_v[i] = in_v[i]; }
+        for (int i = (int)blockIdx.x * T + tid; i < min(n, ((int)blockIdx.x + 1) * T); i += BLOCK) { out_k[i] = in_k[i]; out_v[i] = in_v[i]; }
     }
     work = work && (long long)tile * T < n;
 
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_pass_kernel(SortState* __rest
         const int t0 = tile * T;
         const int shift = 8 * k;
         const unsigned tag = epoch * kSortDigits + (unsigned)k;
-        for (int q = tid; q < (kSortBlock / 64) * kSortBins; q += kSortBlock) (&wave_hist[0][0])[q] = 0;
+        for (int q = tid; q < (BLOCK / 64) * kSortBins; q += BLOCK) (&wave_hist[0][0])[q] = 0;
         uint64_t key[E];
         int val[E];
         unsigned rank[E];
@@ -222,7 +228,8 @@ __global__ __launch_bounds__(kSortBlock) void sort_pass_kernel(SortState* __rest
             key[e] = i < n ? src_k[i] : ~0ull;
             val[e] = i < n ? src_v[i] : 0;
         }
-        const unsigned digit_base = st->base[k][tid];
+        const bool bin_thread = tid < kSortBins;               // (BLOCK >= 256)
+        const unsigned digit_base = bin_thread ? st->base[k][tid] : 0u;
         __syncthreads();
         SORT_TICK(1);
         // stable rank inside the wave's 64 * E pairs: peers = lanes of this round with my digit (8 ballots), the first
@@ -248,16 +255,18 @@ __global__ __launch_bounds__(kSortBlock) void sort_pass_kernel(SortState* __rest
         SORT_TICK(2);
         // bin tid: counts of the four waves -> tile count, exclusive offsets of the waves
         unsigned tile_count = 0;
+        if (bin_thread) {
 #pragma unroll
-        for (int w = 0; w < kSortBlock / 64; ++w) { const unsigned c = wave_hist[w][tid]; wave_hist[w][tid] = tile_count; tile_count += c; }
-        unsigned long long* mine = look + (size_t)tile * kSortBins + tid;
+            for (int w = 0; w < BLOCK / 64; ++w) { const unsigned c = wave_hist[w][tid]; wave_hist[w][tid] = tile_count; tile_count += c; }
+        }
+        unsigned long long* mine = look + (size_t)tile * kSortBins + (bin_thread ? tid : 0);
         const unsigned long long tagw = (unsigned long long)tag << 32;
-        sort_look_store(mine, tagw | (tile == 0 ? kLookPrefix : kLookAgg) | tile_count);
-        const unsigned start = sort_block_excl_scan(tile_count, part);
+        if (bin_thread) sort_look_store(mine, tagw | (tile == 0 ? kLookPrefix : kLookAgg) | tile_count);
+        const unsigned start = sort_block_excl_scan<BLOCK>(tile_count, part);      // (threads beyond the bins add zeros behind them)
         SORT_TICK(3);
         // decoupled look-back over the tiles before this one, 4 words in flight
         unsigned excl = 0;
-        if (tile > 0) {
+        if (tile > 0 && bin_thread) {
             int at = tile - 1, spins = 0;
             bool found = false;
             while (!found) {
@@ -281,8 +290,10 @@ __global__ __launch_bounds__(kSortBlock) void sort_pass_kernel(SortState* __rest
             }
             sort_look_store(mine, tagw | kLookPrefix | (excl + tile_count));
         }
-        bin_start[tid] = start;
-        gbase[tid] = (int)(digit_base + excl) - (int)start;
+        if (bin_thread) {
+            bin_start[tid] = start;
+            gbase[tid] = (int)(digit_base + excl) - (int)start;
+        }
         __syncthreads();
         SORT_TICK(4);
 #pragma unroll
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_pass_kernel(SortState* __rest
         const int nvalid = min(T, n - t0);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const int p = e * kSortBlock + tid;
+            const int p = e * BLOCK + tid;
             if (p < nvalid) {
                 const uint64_t kk = skey[p];
                 const int at = gbase[(unsigned)(kk >> shift) & 255u] + p;
@@ -461,12 +472,18 @@ struct SortBuffers {
     int tiles = 0;
 };
 
-inline int sort_per_thread(int n)
+constexpr int kSortTileBig = 4096, kSortTileSmall = 2048;
+inline int sort_tile_pairs(int n)
 {
-    if (const char* e = std::getenv("NBODY_SORT_E")) return std::atoi(e) == 16 ? 16 : 8;       // developer knob
-    return n >= (1 << 19) ? 16 : 8;        // measured at N = 10^6: 23.3 us per pass with 4096-pair tiles, 26.5 with 2048
+    if (const char* e = std::getenv("NBODY_SORT_E")) return std::atoi(e) == 16 ? kSortTileBig : kSortTileSmall;   // developer knob (pairs per thread at 256 threads)
+    return n >= (1 << 19) ? kSortTileBig : kSortTileSmall;   // measured at N = 10^6: 23.3 us per pass with 4096-pair tiles, 26.5 with 2048
 }
-inline int sort_tiles(int n) { const int t = kSortBlock * sort_per_thread(n); return (n + t - 1) / t; }
+inline int sort_block_threads()
+{
+    if (const char* e = std::getenv("NBODY_SORT_BLOCK")) { const int b = std::atoi(e); if (b == 256 || b == 512 || b == 1024) return b; }   // developer knob
+    return kSortPassBlock;
+}
+inline int sort_tiles(int n) { const int t = sort_tile_pairs(n); return (n + t - 1) / t; }
 inline size_t sort_hist_part_bytes() { return sizeof(unsigned) * (size_t)kSortHistBlocks * kSortDigits * kSortBins; }
 
 // Enqueue the sort: 10 launches, or 9 when `truncated` (5 sweeps + the two run kernels).  tmp_k/tmp_v: n entries each.
@@ -482,11 +499,14 @@ inline bool sort_pairs(const SortBuffers& sb, const uint64_t* in_k, const int* i
     if (hb > kSortHistBlocks) hb = kSortHistBlocks;
     sort_hist_kernel<<<dim3(hb), dim3(kSortBlock), 0, s>>>(in_k, n, sb.hist_part, first);
     sort_plan_kernel<<<dim3(kSortDigits), dim3(1024), 0, s>>>(sb.hist_part, hb, n, sb.state, first);
+    const bool big = sort_tile_pairs(n) == kSortTileBig;
+    const int bt = sort_block_threads();
     for (int k = first; k < kSortDigits; ++k) {
-        if (sort_per_thread(n) == 16)
-            sort_pass_kernel<16><<<dim3(tiles), dim3(kSortBlock), 0, s>>>(sb.state, k, n, in_k, in_v, out_k, out_v, sb.tmp_k, sb.tmp_v, sb.look);
-        else
-            sort_pass_kernel<8><<<dim3(tiles), dim3(kSortBlock), 0, s>>>(sb.state, k, n, in_k, in_v, out_k, out_v, sb.tmp_k, sb.tmp_v, sb.look);
+#define NB_SORT_PASS(E_, B_) sort_pass_kernel<E_, B_><<<dim3(tiles), dim3(B_), 0, s>>>(sb.state, k, n, in_k, in_v, out_k, out_v, sb.tmp_k, sb.tmp_v, sb.look)
+        if (bt == 1024)     { if (big) NB_SORT_PASS(4, 1024); else NB_SORT_PASS(2, 1024); }
+        else if (bt == 512) { if (big) NB_SORT_PASS(8, 512);  else NB_SORT_PASS(4, 512); }
+        else                { if (big) NB_SORT_PASS(16, 256); else NB_SORT_PASS(8, 256); }
+#undef NB_SORT_PASS
     }
     if (truncated) {
         sort_fix_runs_kernel<<<dim3((n + kSortBlock - 1) / kSortBlock), dim3(kSortBlock), 0, s>>>(out_k, out_v, n, sb.state, sb.queue, low63);
