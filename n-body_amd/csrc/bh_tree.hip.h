@@ -1285,9 +1285,8 @@ __global__ __launch_bounds__(kBhBlock) void bh_com_kernel(BhTree t, const BhCoun
 // stays in the tree as the fallback (NBODY_BH_CLIMB_MAX=0).
 // kAgentLoads = false: the cell's children are all leaves, written by the PREVIOUS kernel — ordinary (cached) loads do.
 template <bool kAgentLoads>
-__device__ __forceinline__ void bh_com_cell_agent(const BhTree& t, int c)
+__device__ __forceinline__ void bh_com_cell_agent(const BhTree& t, int c, int self)        // self = t.self[c]
 {
-    const int self = t.self[c];
     unsigned long long xy[4];
     unsigned mz[4];
 #pragma unroll
@@ -1329,17 +1328,20 @@ __global__ __launch_bounds__(kBhBlock) void bh_com_climb_kernel(BhTree t, const 
     int c = scatter ? (int)(threadIdx.x * gridDim.x + blockIdx.x) : (int)(blockIdx.x * kBhBlock + threadIdx.x);
     if (c >= I) return;
     if (t.pend[c] != -1) return;                   // has internal children: the last of them to finish takes it
+    int self = t.self[c];                          // (the node kernel's: ordinary loads)
     for (int hop = 0; hop <= kBhLevels; ++hop) {
-        if (hop == 0) bh_com_cell_agent<false>(t, c);          // a cell without internal children: only leaves below
-        else          bh_com_cell_agent<true>(t, c);
+        if (hop == 0) bh_com_cell_agent<false>(t, c, self);    // a cell without internal children: only leaves below
+        else          bh_com_cell_agent<true>(t, c, self);
         if (c == 0) break;
-        const int p = (t.self[c] - 1) >> 2;
+        const int p = (self - 1) >> 2;
+        const int pself = t.self[p];               // for the next hop: in flight while the stores are acknowledged
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // compiler: nothing moves below
         __builtin_amdgcn_s_waitcnt(0);             // the result stores are acknowledged before the count-off is issued
         const int before = __hip_atomic_fetch_sub(&t.pend[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // compiler: nothing moves above
         if (before != 1) break;
         c = p;
+        self = pself;
     }
 }
 
