@@ -1253,8 +1253,9 @@ __global__ __launch_bounds__(kBhBlock) void bh_com_kernel(BhTree t, const BhCoun
 // (their loads hit the L2), so the host switches there.
 //
 // Visibility across workgroups, which may sit on different XCDs (one L2 each).  The hand-off is, per child:
-//   (1) the child's record {comX, comY | mass} is written ONLY by agent-scope relaxed atomic stores (8 B + 4 B), which
-//       gfx950 emits as `global_store ... sc1`: they write through the XCD's L2 and leave no line behind in it;
+//   (1) the child's record {comX, comY, mass, width} is written ONLY by `global_store_dwordx4 ... sc1` — the instruction
+//       gfx950 emits for an agent-scope relaxed atomic store, in its 16-byte form (rounds 2-3a: an 8- and a 4-byte atomic
+//       store): it writes through the XCD's L2 and leaves no line behind in it;
 //   (2) the storing wave waits for them (s_waitcnt vmcnt(0)) BEFORE (3) it issues the count-off, an agent-scope
 //       atomic read-modify-write on the parent's counter;
 //   (4) the lane whose atomic returned 1 — and nobody else — reads the four children's records, AFTER that return,
@@ -1284,9 +1285,49 @@ __global__ __launch_bounds__(kBhBlock) void bh_com_kernel(BhTree t, const BhCoun
 // 3.2 ms instead of 0.52: every fence writes back / invalidates the whole L2 for everybody.  The per-depth kernel
 // stays in the tree as the fallback (NBODY_BH_CLIMB_MAX=0).
 // kAgentLoads = false: the cell's children are all leaves, written by the PREVIOUS kernel — ordinary (cached) loads do.
+#ifndef NBODY_CLIMB_WIDE
+#define NBODY_CLIMB_WIDE 1
+#endif
 template <bool kAgentLoads>
 __device__ __forceinline__ void bh_com_cell_agent(const BhTree& t, int c, int self)        // self = t.self[c]
 {
+#if NBODY_CLIMB_WIDE
+    // One 16-byte device-scope access per record instead of an 8- and a 4-byte one: the climb beyond the smallest sizes
+    // is bound by the NUMBER of such operations (they are served below the XCD's L2).  The compiler has no 16-byte
+    // atomic load/store, so the instructions are written out: global_load/store_dwordx4 with sc1 = what it emits for
+    // an agent-scope relaxed atomic of 4 or 8 bytes.  Nobody reads a record while it is written (the count-off orders
+    // them), so the access needs no single-copy atomicity of its own.  The record's fourth float, the cell's width, is
+    // the node kernel's and is stored back unchanged.
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f ch[4];
+    const float4* kids = t.A + 1 + 4 * c;
+    const float width = t.A[self].w;               // (the node kernel's; ordinary load, in flight with the children's)
+    if constexpr (kAgentLoads) {
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                     "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
+                     "global_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(ch[0]), "=&v"(ch[1]), "=&v"(ch[2]), "=&v"(ch[3]) : "v"(kids) : "memory");
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float4 a = kids[q]; ch[q] = v4f{a.x, a.y, a.z, a.w}; }
+    }
+    float ms = 0.0f, sx = 0.0f, sy = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {          // as bh_com_cell
+        ms = ms + ch[q].z;
+        sx = __builtin_fmaf(ch[q].x, ch[q].z, sx);
+        sy = __builtin_fmaf(ch[q].y, ch[q].z, sy);
+    }
+    float cx = 0.0f, cy = 0.0f;
+    if (ms > 0.0f) {
+        if (t.com_reciprocal) { const float inv = 1.0f / ms; cx = sx * inv; cy = sy * inv; }
+        else                  { cx = sx / ms; cy = sy / ms; }
+    }
+    const v4f out = {cx, cy, ms, width};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(t.A + self), "v"(out) : "memory");
+#else
     unsigned long long xy[4];
     unsigned mz[4];
 #pragma unroll
@@ -1318,6 +1359,7 @@ __device__ __forceinline__ void bh_com_cell_agent(const BhTree& t, int c, int se
     __hip_atomic_store(rec, (unsigned long long)__float_as_uint(cx) | ((unsigned long long)__float_as_uint(cy) << 32), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(reinterpret_cast<unsigned*>(rec + 1), __float_as_uint(ms), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 
 // scatter != 0 (test switch NBODY_BH_CLIMB_SCATTER): cell c = thread * workgroups + workgroup instead of workgroup * 256 +

@@ -56,7 +56,9 @@ struct Profiler {
 
 constexpr int kMaxSlices = 64;
 constexpr int kBhComSparseTop = 8, kBhComSparseBottom = 24;   // per-depth centre-of-mass launches: depths with few cells (bh_com_kernel)
-constexpr int kBhClimbMax = 1 << 21;         // bodies: up to here the centre-of-mass pass is ONE launch (bh_com_climb_kernel)
+constexpr int kBhClimbMax = 1 << 30;         // bodies: up to here the centre-of-mass pass is ONE launch (bh_com_climb_kernel) — every size since the
+                                             // climb moves 16-byte records (round 3: 191 vs 274 us at 4 x 10^6, 714 vs 864 at 2^24); the per-depth
+                                             // launches stay as the alternative path (NBODY_BH_CLIMB_MAX=0)
 constexpr float kBhSortedThetaScale = 0.6f;     // tools/bh_sorted_scale.py, profiles/r2_bh_sorted_scale.txt
 constexpr int kBhQuadMaxGroups = 6144;      // four waves per group (bh_walk_quad_kernel) up to 49 152 targets at theta >= 1 ...
 constexpr int kBhQuadMinGroups = 3072;      // ... 24 576 at theta <= 0.5, linear in between (measured crossovers)
@@ -337,8 +339,8 @@ int enqueue_bh_build(nbody_ctx* ctx)
     bh_nodes_kernel<<<grid_c, blk, 0, s>>>(b.keys_merged, b.vals_merged, b.cnt, b.base, b.owner, nm, ctx->m, ctx->px, ctx->py,
                                            b.tree, b.ctr, b.overflow_dev, fused ? b.keys_sorted : nullptr,
                                            fused ? b.vals_sorted : nullptr, b.body4, werr);
-    // centre of mass: one launch in which the last child to finish evaluates its parent; for very large trees one
-    // launch per depth (31 launches of >= 4.5 us, but their loads hit the L2: faster above ~2 x 10^6 bodies)
+    // centre of mass: one launch in which the last child to finish evaluates its parent (the per-depth launches of rounds
+    // 1-2 — 31 launches — are the alternative path)
     const char* climb_env = std::getenv("NBODY_BH_CLIMB_MAX");          // developer/test switch, read per enqueue
     const int climb_max = climb_env ? std::atoi(climb_env) : kBhClimbMax;
     if (n <= climb_max) {
