@@ -1040,8 +1040,8 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
     // The four child records of a cell are 64 + 32 contiguous bytes, but a lane that stores its own cell's writes 16
     // (8) bytes at a stride of 64 (32): every store instruction touches 64 lines partially.  Staged through LDS, a
     // wave's 64 cells go out as 4 + 4 fully coalesced stores.
-    __shared__ float4 sA[kBhBlock / 64][256];
-    __shared__ int2 sB[kBhBlock / 64][256];
+    __shared__ float4 sA[kBhBlock / 64][256];                  // 4 KB per wave: first the float4 records, then (reused) the int2 ones
+    int2 bq[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c_wave0 = c - lane;
     if (c_wave0 >= limit) return;                              // wave-uniform
@@ -1148,7 +1148,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
         }
 #if NBODY_NODES_LDS_STORES
         sA[wv][4 * lane + q] = make_float4(cx, cy, cm, width);
-        sB[wv][4 * lane + q] = make_int2(child_base, body);
+        bq[q] = make_int2(child_base, body);
 #else
         t.A[node] = make_float4(cx, cy, cm, width);
         t.B[node] = make_int2(child_base, body);
@@ -1165,7 +1165,21 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int idx = r * 64 + lane;
-        if (idx < records) { t.A[1 + 4 * c_wave0 + idx] = sA[wv][idx]; t.B[1 + 4 * c_wave0 + idx] = sB[wv][idx]; }
+        if (idx < records) t.A[1 + 4 * c_wave0 + idx] = sA[wv][idx];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    int2* sB = reinterpret_cast<int2*>(&sA[wv][0]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sB[4 * lane + q] = bq[q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int idx = r * 64 + lane;
+        if (idx < records) t.B[1 + 4 * c_wave0 + idx] = sB[idx];
     }
 #endif
 }
