@@ -998,6 +998,7 @@ __global__ __launch_bounds__(kBhFixBlock) void bh_prep_small_kernel(const uint64
 #define NBODY_NODES_LDS_STORES 1
 #endif
 constexpr int kBhNodesSmallSpan = 64;         // instances up to which a cell's quadrant boundaries are found by galloping
+constexpr int kBhNodesWindow = 8;             // keys behind the owner that bh_nodes_kernel loads at once
 struct BhWaitErrors { const int* p[3]; };      // SortState::error / ScanState::error of the kernels before (nullptr: not used)
 
 // 4b. one thread per internal cell: box, body range (galloping from the owner: the range of a typical cell is a
@@ -1050,10 +1051,20 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
     if (c >= limit) return;
     {
 #endif
+    // The kernel is a chain of dependent loads under full occupancy, so the chain is kept short: everything a step needs
+    // is requested at once, before anything is stored (keys/vals are not __restrict__: a store in between would pin the
+    // loads behind it).  Round trips of a typical cell: owner -> {keys[i-1 .. i+8], base[i]} -> {keys, base, vals at the
+    // four quadrant starts} -> the leaves' bodies -> stores.  (Round 3; before: ~20 — three galloping searches one after
+    // the other, then the children one by one.)
     const int i = owner[c];
     const uint64_t ki = keys[i];
-    const int lp = i > 0 ? bh_lcp_levels(keys[i - 1], ki) : -1;
-    const int d = lp + 1 + (c - base[i]);                      // depth of this cell, 0..30
+    const uint64_t kprev = i > 0 ? keys[i - 1] : 0;
+    const int base_i = base[i];
+    uint64_t kw[kBhNodesWindow];                               // the keys behind the owner; past the array: behind every cell
+#pragma unroll
+    for (int u = 0; u < kBhNodesWindow; ++u) kw[u] = i + 1 + u < M ? keys[i + 1 + u] : ~0ull;
+    const int lp = i > 0 ? bh_lcp_levels(kprev, ki) : -1;
+    const int d = lp + 1 + (c - base_i);                       // depth of this cell, 0..30
     const int shift = 2 * (kBhLevels - d);
     const uint64_t prefix = d ? ki >> shift : 0;
 
@@ -1065,26 +1076,43 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
         if (q & 1) tlx = mx; else brx = mx;
         if (q & 2) tly = my; else bry = my;
     }
-    if (c == 0) {
-        t.A[0] = make_float4(0.0f, 0.0f, 0.0f, brx - tlx);
-        t.B[0] = make_int2(1, -1);
-        t.self[0] = 0;
-    }
-    t.depth[c] = (uint8_t)d;
 
     // body range [i, e) of the cell and its quadrant boundaries
-    const int e = d ? bh_gallop_lower_bound(keys, i + 1, M, (prefix + 1) << shift) : M;
+    int e = M;
+    if (d) {
+        const uint64_t bound = (prefix + 1) << shift;
+        int inside = 0;                                        // sorted: the members among kw[] are its first `inside` entries
+#pragma unroll
+        for (int u = 0; u < kBhNodesWindow; ++u) inside += kw[u] < bound ? 1 : 0;
+        e = inside < kBhNodesWindow ? i + 1 + inside : bh_gallop_lower_bound(keys, i + 1 + kBhNodesWindow, M, bound);
+    }
     const int cshift = shift - 2;
     int s[5];
     s[0] = i;
     s[4] = e;
-    if (e - i <= kBhNodesSmallSpan) {
+    if (e - i <= kBhNodesWindow + 1) {
+        // the whole cell is in registers (nearly every cell: a typical one spans a few bodies)
+        int below[4] = {0, 0, 0, 0};
+        {
+            const int dg = (int)((ki >> cshift) & 3);
+#pragma unroll
+            for (int q = 1; q < 4; ++q) below[q] += dg < q ? 1 : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kBhNodesWindow; ++u) {
+            const int dg = (int)((kw[u] >> cshift) & 3);
+#pragma unroll
+            for (int q = 1; q < 4; ++q) below[q] += (u < e - i - 1 && dg < q) ? 1 : 0;
+        }
+#pragma unroll
+        for (int q = 1; q < 4; ++q) s[q] = i + below[q];
+    } else if (e - i <= kBhNodesSmallSpan) {
 #pragma unroll
         for (int q = 1; q < 4; ++q) s[q] = bh_gallop_lower_bound(keys, s[q - 1], e, ((prefix << 2) | (uint64_t)q) << cshift);
     } else {
         // A cell near the root spans 10^4-10^6 instances; three galloping searches, each starting where the one before
-        // ended, are ~100 dependent loads there, and at N = 10^6 — one wave per SIMD — those few lanes ARE the kernel's
-        // duration.  Three binary searches over [i, e) side by side: their loads are independent, the chain is log2(span).
+        // ended, are ~100 dependent loads there.  Three binary searches over [i, e) side by side: their loads are
+        // independent, the chain is log2(span).
         int lo[4], hi[4];
         uint64_t v[4];
 #pragma unroll
@@ -1101,32 +1129,54 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
         for (int q = 1; q < 4; ++q) s[q] = lo[q];
     }
 
-    const float mx = (tlx + brx) / 2.0f;
+    // what the four children need, requested together (an empty quadrant at the end of the array reads entry M - 1)
+    uint64_t ka[4], kb[4];
+    int bs[4], vl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = s[q] < M - 1 ? s[q] : M - 1;
+        ka[q] = j > 0 ? keys[j - 1] : 0;
+        kb[q] = keys[j];
+        bs[q] = base[j];
+        vl[q] = vals[j];
+    }
+    int child_base[4], body[4];
     int internal_children = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int cntq = s[q + 1] - s[q];
+        child_base[q] = -1;
+        body[q] = -1;
+        if (cntq >= 2 && d + 1 < kBhLevels) {
+            const int lpq = s[q] > 0 ? bh_lcp_levels(ka[q], kb[q]) : -1;
+            const int cc = bs[q] + d - lpq;                    // id of the internal child
+            if (cc < t.cap_internal) { child_base[q] = 1 + 4 * cc; ++internal_children; }
+            else body[q] = vl[q];                              // pool exhausted: keep one body (benchmark.cpp:102)
+        } else if (cntq >= 1) {
+            body[q] = vl[q];                                   // leaf
+        }
+    }
+    float4 pb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pb[q] = body4[body[q] >= 0 ? body[q] : vl[q]];      // (always a valid index; unused when there is no body)
+
+    if (c == 0) {
+        t.A[0] = make_float4(0.0f, 0.0f, 0.0f, brx - tlx);
+        t.B[0] = make_int2(1, -1);
+        t.self[0] = 0;
+    }
+    t.depth[c] = (uint8_t)d;
+    const float mx = (tlx + brx) / 2.0f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int node = 1 + 4 * c + q;
         const float ctlx = (q & 1) ? mx : tlx, cbrx = (q & 1) ? brx : mx;
         const float width = cbrx - ctlx;                       // benchmark.cpp:251
         const int cntq = s[q + 1] - s[q];
-        int child_base = -1, body = -1;
         float cx = 0.0f, cy = 0.0f, cm = 0.0f;
-        if (cntq >= 2 && d + 1 < kBhLevels) {
-            const int sq = s[q];
-            const int lpq = sq > 0 ? bh_lcp_levels(keys[sq - 1], keys[sq]) : -1;
-            const int cc = base[sq] + d - lpq;                 // id of the internal child
-            if (cc < t.cap_internal) {
-                child_base = 1 + 4 * cc;
-                t.self[cc] = node;
-                ++internal_children;
-            } else {                                           // pool exhausted: keep one body (benchmark.cpp:102)
-                body = vals[sq];
-            }
-        } else if (cntq >= 1) {
-            body = vals[s[q]];                                  // leaf
-        }
-        if (body >= 0) { const float4 p = body4[body]; cx = p.x; cy = p.y; cm = p.z; }   // benchmark.cpp:89-92
-        if (child_base < 0 && cntq >= 2) {
+        if (child_base[q] >= 0) t.self[(child_base[q] - 1) >> 2] = node;
+        if (body[q] >= 0) { cx = pb[q].x; cy = pb[q].y; cm = pb[q].z; }   // benchmark.cpp:89-92
+        if (child_base[q] < 0 && cntq >= 2) {
             // Several bodies in one cell that is not split further: closer together than the finest cell (the path
             // key has 31 levels: 800/2^31 = 3.7e-7 at spread 400) or the pool is exhausted.  The reference keeps
             // splitting such a cell (to its depth ~40-150, for coincident bodies until ITS pool is exhausted,
@@ -1146,12 +1196,13 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
             cm = ms;
             if (ms > 0.0f) { cx = sx / ms; cy = sy / ms; }
         }
+        const int child_base_q = child_base[q], body_q = body[q];
 #if NBODY_NODES_LDS_STORES
         sA[wv][4 * lane + q] = make_float4(cx, cy, cm, width);
-        bq[q] = make_int2(child_base, body);
+        bq[q] = make_int2(child_base_q, body_q);
 #else
         t.A[node] = make_float4(cx, cy, cm, width);
-        t.B[node] = make_int2(child_base, body);
+        t.B[node] = make_int2(child_base_q, body_q);
 #endif
     }
     t.pend[c] = internal_children ? internal_children : -1;
