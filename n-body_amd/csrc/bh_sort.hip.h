@@ -100,22 +100,25 @@ __device__ __forceinline__ unsigned sort_block_excl_scan(unsigned v, unsigned* p
     return before + incl - v;
 }
 
-// chunk b of the keys -> part[b][digit position][bin]
-__global__ __launch_bounds__(kSortBlock) void sort_hist_kernel(const uint64_t* __restrict__ keys, int n, unsigned* __restrict__ part, int first)
+// chunk b of the keys -> part[b][digit position][bin].  1024 threads: the kernel is one workgroup per CU (256 chunks), and
+// its LDS atomics pile up on a few bins in the high digit positions — four waves per SIMD overlap what one cannot
+// (256 -> 1024 threads: 2^24 keys 82 -> 42 us, 4 x 10^6 19.5 -> 10.3, 10^6 6.2 -> 5.0).
+constexpr int kSortHistThreads = 1024;
+__global__ __launch_bounds__(kSortHistThreads) void sort_hist_kernel(const uint64_t* __restrict__ keys, int n, unsigned* __restrict__ part, int first)
 {
     __shared__ unsigned h[kSortDigits][kSortBins];
     const int tid = threadIdx.x;
-    for (int q = tid; q < kSortDigits * kSortBins; q += kSortBlock) (&h[0][0])[q] = 0;
+    for (int q = tid; q < kSortDigits * kSortBins; q += kSortHistThreads) (&h[0][0])[q] = 0;
     __syncthreads();
-    const int per = ((n + (int)gridDim.x - 1) / (int)gridDim.x + kSortBlock - 1) / kSortBlock * kSortBlock;
+    const int per = ((n + (int)gridDim.x - 1) / (int)gridDim.x + kSortHistThreads - 1) / kSortHistThreads * kSortHistThreads;
     const int b0 = (int)blockIdx.x * per, b1 = min(n, b0 + per);
-    for (int i0 = b0; i0 < b1; i0 += 4 * kSortBlock) {
+    for (int i0 = b0; i0 < b1; i0 += 4 * kSortHistThreads) {
         uint64_t k[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int i = i0 + u * kSortBlock + tid; k[u] = i < b1 ? keys[i] : 0; }
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * kSortHistThreads + tid; k[u] = i < b1 ? keys[i] : 0; }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (i0 + u * kSortBlock + tid < b1) {
+            if (i0 + u * kSortHistThreads + tid < b1) {
 #pragma unroll
                 for (int d = 0; d < kSortDigits; ++d)
                     if (d >= first) atomicAdd(&h[d][(unsigned)(k[u] >> (8 * d)) & 255u], 1u);
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_hist_kernel(const uint64_t* _
     }
     __syncthreads();
     unsigned* g = part + (size_t)blockIdx.x * (kSortDigits * kSortBins);
-    for (int q = tid; q < kSortDigits * kSortBins; q += kSortBlock) g[q] = (&h[0][0])[q];
+    for (int q = tid; q < kSortDigits * kSortBins; q += kSortHistThreads) g[q] = (&h[0][0])[q];
 }
 
 // workgroup d = digit position d: total histogram (1024 threads: four take a quarter of the chunks of one bin each),
@@ -497,7 +500,7 @@ inline bool sort_pairs(const SortBuffers& sb, const uint64_t* in_k, const int* i
     const int tiles = sort_tiles(n);
     int hb = (n + 8 * kSortBlock - 1) / (8 * kSortBlock);
     if (hb > kSortHistBlocks) hb = kSortHistBlocks;
-    sort_hist_kernel<<<dim3(hb), dim3(kSortBlock), 0, s>>>(in_k, n, sb.hist_part, first);
+    sort_hist_kernel<<<dim3(hb), dim3(kSortHistThreads), 0, s>>>(in_k, n, sb.hist_part, first);
     sort_plan_kernel<<<dim3(kSortDigits), dim3(1024), 0, s>>>(sb.hist_part, hb, n, sb.state, first);
     const bool big = sort_tile_pairs(n) == kSortTileBig;
     const int bt = sort_block_threads();
