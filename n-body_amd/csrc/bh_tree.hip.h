@@ -727,14 +727,17 @@ __global__ __launch_bounds__(kBhBlock) void bh_owner_kernel(const int* __restric
 // tiles examined per step by wave 0.  Waits are bounded as in bh_sort.hip.h.  The last workgroup to finish resets the
 // ticket and opens the next epoch.
 struct ScanState { unsigned epoch; int ticket; int done; int error; };
-constexpr int kBhScanRounds = 8;
+constexpr int kBhScanRounds = 8;             // rounds of 64 instances per wave: tile = 256 x R.  Large builds use 16 (half the tiles for the
+constexpr int kBhScanRoundsLarge = 16;       // look-back to cross: 2^24 229 -> 181 us, 4 x 10^6 67 -> 54; 10^6 22.2 -> 23.8, 32: slower everywhere)
+constexpr int kBhScanLargeFrom = 1 << 21;    // instances from which the large tile is used
 
+template <int R>
 __global__ __launch_bounds__(kBhBlock) void bh_cells_scan_kernel(const uint64_t* __restrict__ keys, int nm,
                                                                  const BhCounters* __restrict__ ctr, ScanState* __restrict__ ss,
                                                                  unsigned long long* __restrict__ look, int* __restrict__ cnt,
                                                                  int* __restrict__ base, int* __restrict__ owner, int cap_internal)
 {
-    constexpr int R = kBhScanRounds, T = kBhBlock * R;
+    constexpr int T = kBhBlock * R;
     __shared__ int s_tile;
     __shared__ int wave_total[kBhBlock / 64];
     __shared__ int s_excl;
@@ -782,6 +785,8 @@ __global__ __launch_bounds__(kBhBlock) void bh_cells_scan_kernel(const uint64_t*
         if (wave == 0) {
             const unsigned long long tagw = (unsigned long long)epoch << 32;
             if (lane == 0) sort_look_store(look + tile, tagw | (tile == 0 ? kLookPrefix : kLookAgg) | (unsigned)total);
+            // (Tried, round 3: 4 x 64 predecessor words per look-back step instead of 64 — no gain, 188 against 181 us at 2^24: the
+            // look-back is not what bounds this kernel; fewer, larger tiles are what helped.)
             int excl = 0, at = tile - 1, spins = 0;
             while (at >= 0) {
                 const int j = at - lane;

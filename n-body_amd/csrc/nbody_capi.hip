@@ -327,9 +327,15 @@ int enqueue_bh_build(nbody_ctx* ctx)
             HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b.scan_tmp, b.scan_bytes, b.cnt, b.base, nm, s));
             bh_owner_kernel<<<grid_m, blk, 0, s>>>(b.cnt, b.base, nm, b.ctr, b.owner, b.tree.cap_internal);
         } else {
-            constexpr int kScanTile = kBhBlock * kBhScanRounds;
-            bh_cells_scan_kernel<<<dim3((nm + kScanTile - 1) / kScanTile), blk, 0, s>>>(b.keys_merged, nm, b.ctr, b.scan_state, b.scan_look,
-                                                                                       b.cnt, b.base, b.owner, b.tree.cap_internal);
+            if (nm >= kBhScanLargeFrom) {
+                constexpr int kScanTile = kBhBlock * kBhScanRoundsLarge;
+                bh_cells_scan_kernel<kBhScanRoundsLarge><<<dim3((nm + kScanTile - 1) / kScanTile), blk, 0, s>>>(
+                    b.keys_merged, nm, b.ctr, b.scan_state, b.scan_look, b.cnt, b.base, b.owner, b.tree.cap_internal);
+            } else {
+                constexpr int kScanTile = kBhBlock * kBhScanRounds;
+                bh_cells_scan_kernel<kBhScanRounds><<<dim3((nm + kScanTile - 1) / kScanTile), blk, 0, s>>>(
+                    b.keys_merged, nm, b.ctr, b.scan_state, b.scan_look, b.cnt, b.base, b.owner, b.tree.cap_internal);
+            }
         }
     }
     BhWaitErrors werr{{nullptr, nullptr, nullptr}};
