@@ -1498,6 +1498,13 @@ inline int bh_walk_groups_per_wave(int targets)
 // oracle's: the approximate ratio decides only when it is further than 4e-6 (relative; > 10x its error bound of
 // ~3.5 ulp) from theta, otherwise the wave redoes that node with the IEEE expressions.  So the visit pattern
 // and the counters are identical in both modes and only the accepted terms differ, by a few ulp each.
+// Votes.  A predicate that reaches a ballot as a loop-carried bool or as an OR of two comparisons lives in a lane mask, and
+// the compiler then materialises it as 0/1 in a VGPR (v_cndmask) and compares that with 0 again (v_cmp_ne) to get the
+// ballot — two VALU instructions in a VALU-bound walk.  So the walk votes on FRESH comparisons: the loop's `active` is an
+// int (one v_cmp_ne), and "far or not a target" is ballot(far) | ~live_mask.
+__device__ __forceinline__ unsigned long long bh_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool bh_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 template <bool kFast>
 __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
 {
@@ -1523,8 +1530,8 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     unsigned visits = 0, accepts = 0;
 
     // is any lane of my group a real target?
-    const unsigned long long live_mask = __ballot(live);
-    bool active = ((live_mask >> grp_shift) & 0xFFull) != 0;
+    const unsigned long long live_mask = bh_ballot(live);
+    int active = ((live_mask >> grp_shift) & 0xFFull) != 0 ? 1 : 0;   // an int on purpose: see bh_ballot
     int node = 0, sp = 0;
     float4 a = w.A[0];
     int2 b = w.B[0];
@@ -1532,7 +1539,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     // (Tried, round 3: a per-lane `while (active)` loop, finished groups masked off by the hardware instead of by the
     // `if (active)` below.  It removes the ~10 register copies per iteration that the compiler makes around the divergent
     // region, and is SLOWER: walk 2.07 against 1.99 ms at N = 10^6, 0.46 against 0.385 at 65 536 — same-box A/B.)
-    while (__any(active)) {
+    while (bh_ballot(active != 0) != 0ull) {
         ++iters;
         if (active) {
             // (Tried: requesting the records of both likely successors — next sibling and last child — before this
@@ -1555,9 +1562,9 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
                 float inv = __builtin_amdgcn_rcpf(d + eps);
                 const float q = a.w * inv;
                 bool far = q < w.theta;
-                if (__any(__builtin_fabsf(q - w.theta) <= vote_margin))              // rare: ~1e-4 of the waves' visits
+                if (bh_any(__builtin_fabsf(q - w.theta) <= vote_margin))              // rare: ~1e-4 of the waves' visits
                     far = (a.w / (__builtin_sqrtf(d2) + eps)) < w.theta;
-                const unsigned long long fm = __ballot(far || !live);
+                const unsigned long long fm = bh_ballot(far) | ~live_mask;      // (= ballot(far || !live), one vote on a fresh compare)
                 const bool all_far = ((fm >> grp_shift) & 0xFFull) == 0xFFull;
                 if (b.x < 0 || all_far) {                       // :266 leaf or every lane far
                     ++accepts;
@@ -1569,7 +1576,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
                     if constexpr (kFast) {
                         const float sd = __builtin_fmaxf(d, ri);    // clamp radius is the TARGET's only (:201-202)
                         f = a.z * __builtin_amdgcn_rcpf(__builtin_fmaf(sd, sd, soft2));
-                    } else if (w.exact_core && __ballot(!(d2 >= kCoreD2Min && d2 <= kCoreD2Max)) == 0ull) {
+                    } else if (w.exact_core && bh_ballot(!(d2 >= kCoreD2Min && d2 <= kCoreD2Max)) == 0ull) {
                         d = core_sqrt_rn(d2, d);                                    // :193-194
                         const float sd = __builtin_fmaxf(d, ri);
                         f = core_div_rn(a.z, __builtin_fmaf(sd, sd, soft2));        // :203-209
@@ -1599,7 +1606,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
                 a = w.A[node];
                 b = w.B[node];
             } else {
-                active = false;
+                active = 0;
             }
         }
     }
@@ -1757,6 +1764,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBODY_QUAD_
     const float vote_margin = 4e-6f * w.theta;
     const unsigned long long below_me = (1ull << lane) - 1ull;
     const unsigned long long below_slot = (1ull << (slot * 8)) - 1ull;
+    const unsigned long long not_live_mask = ~bh_ballot(live);
     float ax = 0.0f, ay = 0.0f;
     unsigned visits = 0, accepts = 0;                    // wave-uniform
     int presplit = 0;
@@ -1771,9 +1779,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBODY_QUAD_
         const float d2 = __builtin_fmaf(dx, dx, dy * dy);
         const float q = a.w * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(d2) + eps);
         bool far = q < w.theta;
-        if (__any(__builtin_fabsf(q - w.theta) <= vote_margin))
+        if (bh_any(__builtin_fabsf(q - w.theta) <= vote_margin))
             far = (a.w / (__builtin_sqrtf(d2) + eps)) < w.theta;
-        const unsigned long long fm = __ballot(far || !live);
+        const unsigned long long fm = bh_ballot(far) | not_live_mask;     // (= ballot(far || !live): see bh_ballot)
         const bool all_far = ((fm >> (slot * 8)) & 0xFFull) == 0xFFull;
         const bool massive = act && a.z != 0.0f;
         accept = massive && (b.x < 0 || all_far);
@@ -1810,14 +1818,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBODY_QUAD_
             for (int u = 0; u < kWidePerSlot; ++u) {
                 bool accept, open;
                 vote(a[u], b[u], act[u], accept, open);
-                const unsigned long long am = __ballot(accept && t == 0);
+                const unsigned long long am = bh_ballot(accept && t == 0);
                 const int apos = na + __popcll(am & below_me);
                 if (accept && t == 0 && apos < kAcc) {
                     S.akey[apos] = key[u] << (__builtin_clzll(key[u]) - 1);    // left-aligned: sentinel at bit 62
                     S.anode[apos] = node[u];
                 }
                 na += __popcll(am);
-                const unsigned long long om = __ballot(open && t == 0);
+                const unsigned long long om = bh_ballot(open && t == 0);
                 const int base = sp + 4 * __popcll(om & below_slot);
                 if (open && t < 4 && base + t < kStk) {
                     S.pnode[base + t] = b[u].x + t;                            // children 0..3 (:272-274)
@@ -1854,7 +1862,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBODY_QUAD_
             inv = __builtin_amdgcn_rcpf(d + eps);
             const float sd = __builtin_fmaxf(d, ri);
             f = a.z * __builtin_amdgcn_rcpf(__builtin_fmaf(sd, sd, soft2));
-        } else if (w.exact_core && __ballot(!(d2 >= kCoreD2Min && d2 <= kCoreD2Max)) == 0ull) {
+        } else if (w.exact_core && bh_ballot(!(d2 >= kCoreD2Min && d2 <= kCoreD2Max)) == 0ull) {
             // correctly rounded, by exact_core.hip.h's shorter sequences: every lane's d^2 is in their range
             d = core_sqrt_rn(d2, __builtin_amdgcn_sqrtf(d2));
             const float sd = __builtin_fmaxf(d, ri);                   // :201-202
@@ -1941,7 +1949,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBODY_QUAD_
     const int2 b0 = w.B[0];
     bool root_accept, root_open;
     vote(a0, b0, true, root_accept, root_open);
-    root_open = __any(root_open && slot == 0);             // (identical in every slot; made wave-uniform for the compiler)
+    root_open = bh_any(root_open && slot == 0);             // (identical in every slot; made wave-uniform for the compiler)
     if (!root_open) {
         if (wv != 0) return;
         run_tasks(0, 0);                                   // a leaf, an accepted or a massless root: one visit, wave 0 alone
