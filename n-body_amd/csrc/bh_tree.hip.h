@@ -1434,6 +1434,9 @@ __device__ __forceinline__ void bh_com_cell_agent(const BhTree& t, int c, int se
 
 // scatter != 0 (test switch NBODY_BH_CLIMB_SCATTER): cell c = thread * workgroups + workgroup instead of workgroup * 256 +
 // thread, so that the consecutive ids of a subtree — parent and children — sit in DIFFERENT workgroups on different XCDs.
+// (Tried, round 3: the first hop taken by the wave together — leaf-only children of one parent have consecutive ids and sit
+// in adjacent lanes, so each run of lanes with the same parent counted off once, with the run's length: a third of the
+// atomics.  No gain: 51.6 -> 50.7 us at N = 10^6, 703 -> 704 at 2^24.  The atomics are not what the climb waits for.)
 __global__ __launch_bounds__(kBhBlock) void bh_com_climb_kernel(BhTree t, const BhCounters* __restrict__ ctr, int scatter)
 {
     const int I = ctr->internal;
