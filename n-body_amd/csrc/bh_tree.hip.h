@@ -1366,12 +1366,12 @@ __device__ __forceinline__ void bh_com_cell_agent(const BhTree& t, int c, int se
     // is bound by the NUMBER of such operations (they are served below the XCD's L2).  The compiler has no 16-byte
     // atomic load/store, so the instructions are written out: global_load/store_dwordx4 with sc1 = what it emits for
     // an agent-scope relaxed atomic of 4 or 8 bytes.  Nobody reads a record while it is written (the count-off orders
-    // them), so the access needs no single-copy atomicity of its own.  The record's fourth float, the cell's width, is
-    // the node kernel's and is stored back unchanged.
+    // them), so the access needs no single-copy atomicity of its own.  The store is the 12-byte form (dwordx3): the
+    // record's fourth float, the cell's width, is the node kernel's and stays (reading it to store it back — the first
+    // version — was a scattered 64-byte fetch per cell: 0.8 of the 2.1 GB the climb fetched at N = 2^24).
     typedef float v4f __attribute__((ext_vector_type(4)));
     v4f ch[4];
     const float4* kids = t.A + 1 + 4 * c;
-    const float width = t.A[self].w;               // (the node kernel's; ordinary load, in flight with the children's)
     if constexpr (kAgentLoads) {
         asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
                      "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
@@ -1395,8 +1395,9 @@ __device__ __forceinline__ void bh_com_cell_agent(const BhTree& t, int c, int se
         if (t.com_reciprocal) { const float inv = 1.0f / ms; cx = sx * inv; cy = sy * inv; }
         else                  { cx = sx / ms; cy = sy / ms; }
     }
-    const v4f out = {cx, cy, ms, width};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(t.A + self), "v"(out) : "memory");
+    typedef float v3f __attribute__((ext_vector_type(3)));
+    const v3f out = {cx, cy, ms};                  // 12 bytes: the record's fourth float, the cell's width, is the node kernel's
+    asm volatile("global_store_dwordx3 %0, %1, off sc1" : : "v"(t.A + self), "v"(out) : "memory");
 #else
     unsigned long long xy[4];
     unsigned mz[4];
