@@ -1134,6 +1134,11 @@ __global__ __launch_bounds__(kBhBlock) void bh_nodes_kernel(const uint64_t* keys
         for (int q = 1; q < 4; ++q) s[q] = lo[q];
     }
 
+    // (Tried, round 3: every cell computing its OWN node index — parent = c - 1, or, for an owner's shallowest cell, found
+    // through a window of the 8 keys before the owner — and storing it coalesced, instead of the parent's scattered
+    // t.self[child] = node below, which the counters suggested as a third of the kernel's traffic.  Correct (all tree tests),
+    // and slower: 65 -> 85 us at N = 10^6, 1067 -> 1345 at 2^24 — nine more 64-bit registers and loads per cell cost more
+    // occupancy than the scattered stores cost bandwidth.)
     // what the four children need, requested together (an empty quadrant at the end of the array reads entry M - 1)
     uint64_t ka[4], kb[4];
     int bs[4], vl[4];
