@@ -647,7 +647,8 @@ __global__ __launch_bounds__(kBhBlock) void bh_merge_kernel(const uint64_t* __re
     const int p1 = min(n, t0 + kBhBlock * kBhMergePer);         // primaries of this workgroup: [t0, p1)
     if (tid < 2 && t0 < p1) {
         const uint64_t k = keys[tid == 0 ? t0 : p1 - 1];
-        int lo = 0, hi = gcap;                                 // second instances with a smaller key
+        const int ghosts = ctr->ghosts;                        // (behind them the buffer is padding, which sorts last)
+        int lo = 0, hi = ghosts < gcap ? ghosts : gcap;        // second instances with a smaller key
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (gkeys[mid] < k) lo = mid + 1; else hi = mid; }
         s_lo[tid] = lo;
     }
