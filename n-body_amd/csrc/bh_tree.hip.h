@@ -645,6 +645,15 @@ __global__ __launch_bounds__(kBhBlock) void bh_merge_kernel(const uint64_t* __re
     // padding and the out-of-box bodies have it set and sort behind them); nobody else in this launch reads ctr
     if (t0 == 0 && tid == 0) ctr->valid += ctr->ghosts < gcap ? ctr->ghosts : gcap;
     const int p1 = min(n, t0 + kBhBlock * kBhMergePer);         // primaries of this workgroup: [t0, p1)
+    // the workgroup's own pairs are requested first: they are in flight while two lanes walk their dependent probes
+    uint64_t kk[kBhMergePer];
+    int vv[kBhMergePer];
+#pragma unroll
+    for (int u = 0; u < kBhMergePer; ++u) {
+        const int t = t0 + u * kBhBlock + tid;
+        kk[u] = t < n ? keys[t] : 0;
+        vv[u] = t < n ? vals[t] : 0;
+    }
     if (tid < 2 && t0 < p1) {
         const uint64_t k = keys[tid == 0 ? t0 : p1 - 1];
         const int ghosts = ctr->ghosts;                        // (behind them the buffer is padding, which sorts last)
@@ -657,11 +666,11 @@ __global__ __launch_bounds__(kBhBlock) void bh_merge_kernel(const uint64_t* __re
     for (int u = 0; u < kBhMergePer; ++u) {
         const int t = t0 + u * kBhBlock + tid;
         if (t < n) {
-            const uint64_t k = keys[t];
+            const uint64_t k = kk[u];
             int lo = s_lo[0], hi = s_lo[1];
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (gkeys[mid] < k) lo = mid + 1; else hi = mid; }
             okeys[t + lo] = k;
-            ovals[t + lo] = vals[t];
+            ovals[t + lo] = vv[u];
         } else {
             bh_merge_one(t, keys, vals, n, gkeys, gvals, gcap, okeys, ovals);
         }
