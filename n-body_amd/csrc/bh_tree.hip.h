@@ -131,17 +131,38 @@ __global__ __launch_bounds__(kBhBlock) void bh_keys_kernel(const float* __restri
             key = kBhInvalidKey | ((uint64_t)(uint32_t)i << 24);
         } else {
             inside = true;
-            key = 0;
+            // The kernel is VALU-bound (31 levels for every body), so the level is written for the instruction count
+            // (round 3: 24 -> 16 vector instructions per level).  Key bits go in by doubling-and-adding into two 32-bit
+            // words (levels 0-14 and 15-30).  The first tie level is COUNTED: a coordinate on a split line takes the lower
+            // child, becomes the upper bound of its cell and stays it (br == x from then on), and before that br > x — so
+            // the number of levels after which br != x is the first level with x == m, 31 when there is none.  (A
+            // coordinate ON the box's upper edge has br == x from the start and is recorded at level 0: a lower bound,
+            // which is all the record's readers need — they filter with it and take the exact ties from a descent.)
+            unsigned khi = 0, klo = 0;
+            tx = 0; ty = 0;
 #pragma unroll 1
-            for (int l = 0; l < kBhLevels; ++l) {
+            for (int l = 0; l < 15; ++l) {
                 const float mx = (tlx + brx) / 2.0f, my = (tly + bry) / 2.0f;    // benchmark.cpp:98-99
-                tx = (x == mx && tx == kBhLevels) ? l : tx;
-                ty = (y == my && ty == kBhLevels) ? l : ty;
-                const int qx = x > mx, qy = y > my;            // on the line -> lower child
-                key = (key << 2) | (uint64_t)(qy * 2 + qx);    // TL, TR, BL, BR (benchmark.cpp:105-108)
+                const bool qx = x > mx, qy = y > my;           // on the line -> lower child
+                khi = khi + khi + (qy ? 1u : 0u);              // TL, TR, BL, BR (benchmark.cpp:105-108): bits (y, x)
+                khi = khi + khi + (qx ? 1u : 0u);
                 tlx = qx ? mx : tlx; brx = qx ? brx : mx;
                 tly = qy ? my : tly; bry = qy ? bry : my;
+                tx += brx != x ? 1 : 0;
+                ty += bry != y ? 1 : 0;
             }
+#pragma unroll 1
+            for (int l = 15; l < kBhLevels; ++l) {
+                const float mx = (tlx + brx) / 2.0f, my = (tly + bry) / 2.0f;
+                const bool qx = x > mx, qy = y > my;
+                klo = klo + klo + (qy ? 1u : 0u);
+                klo = klo + klo + (qx ? 1u : 0u);
+                tlx = qx ? mx : tlx; brx = qx ? brx : mx;
+                tly = qy ? my : tly; bry = qy ? bry : my;
+                tx += brx != x ? 1 : 0;
+                ty += bry != y ? 1 : 0;
+            }
+            key = ((uint64_t)khi << 32) | klo;
         }
         keys[i] = key;
         vals[i] = i;
