@@ -389,7 +389,7 @@ def main():
                          "kernel_ms_max": float(k_all.max()) if len(k_all) else None,
                          "clock": clock, "frac_at_measured_clock": frac_at_clock,
                          "note": "FP32 vector (no MFMA: elementwise-transcendental pair loop); algorithmic flop = "
-                                 "20 x owned targets x N sources per launch (rank 0); integrate_kernel "
+                                 "20 x owned targets x N sources per launch (rank 0); integrate4_kernel "
                                  f"{integ_ms / max(1, integ_launches) * 1e3:.1f} us/launch"},
         }
         # second kernel of the step: j-slice reduction + Euler, HBM-bound.  Algorithmic bytes per owned target:
@@ -397,10 +397,11 @@ def main():
         i_ms = integ_ms / max(1, integ_launches)
         i_gbs = (8.0 * info["j_slices"] + 40.0) * my_targets / (i_ms * 1e-3) / 1e9 if i_ms > 0 else 0.0
         line["roofline_integrate"] = {"bound": "hbm", "achieved": i_gbs, "peak": 8000.0, "unit": "GB/s", "frac": i_gbs / 8000.0,
-                                      "traffic": None, "kernel": "integrate_kernel", "kernel_ms": i_ms,
+                                      "traffic": None, "kernel": "integrate4_kernel", "kernel_ms": i_ms,
                                       "launches": int(integ_launches),
-                                      "note": "hipEvent pairs add ~3 us to a kernel this short: rocprofv3 shows 21.1 us = 5.2 TB/s "
-                                              "for the same launch (profiles/r3_naive_n1m_kernel_stats.csv)"}
+                                      "note": "hipEvent pairs add ~3 us to a kernel this short: rocprofv3 shows 18.3 us = 6.0 TB/s "
+                                              "for the same launch (profiles/r3_naive_n1m_integrate4_kernel_stats.txt; "
+                                              "the one-body-per-thread kernel it replaced: 21.1 us)"}
         if world == 1 and n == 1 << 20 and info["j_slices"] == 8:
             # HBM bytes per force launch from the committed PMC passes of this very command (FETCH_SIZE KiB x2 on
             # gfx950 + WRITE_SIZE KiB); counters cannot be read from inside the process, so this is not live

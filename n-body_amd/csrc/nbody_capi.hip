@@ -253,7 +253,11 @@ int enqueue_integrate(nbody_ctx* ctx, int advance)
     EventPair* ep;
     int rc = profile_begin(ctx, 1, &ep);
     if (rc) return rc;
-    integrate_kernel<<<dim3((nt + 255) / 256), dim3(256), 0, ctx->stream>>>(a);
+    // every array is its own hipMalloc and i_stride a multiple of 64: a quad is 16-byte aligned iff i_begin is
+    if (a.i_begin % 4 == 0 && a.i_stride % 4 == 0 && !std::getenv("NBODY_INTEGRATE_SCALAR"))   // (developer/test switch)
+        integrate4_kernel<<<dim3(((nt + 3) / 4 + 255) / 256), dim3(256), 0, ctx->stream>>>(a);
+    else
+        integrate_kernel<<<dim3((nt + 255) / 256), dim3(256), 0, ctx->stream>>>(a);
     HIP_TRY(hipGetLastError());
     return profile_end(ctx, 1, ep);
 }
