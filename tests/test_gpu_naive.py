@@ -327,6 +327,37 @@ def test_two_shards_equal_one(nb, O):
             s.close()
 
 
+@pytest.mark.parametrize("n,shard", [(5003, None), (5003, (0, 4997)), (5003, (1000, 2501)), (5003, (1002, 2501)),
+                                     (4099, (4096, 3)), (70001, (8, 69993)), (3, None)])
+def test_quad_euler_kernel_equals_the_one_body_kernel(nb, O, n, shard, monkeypatch):
+    """integrate4_kernel (four bodies per thread, 16-byte accesses; picked when the shard starts at a multiple of 4)
+    against integrate_kernel (one body per thread; NBODY_INTEGRATE_SCALAR, and the shard that starts at 1002): the state
+    after one step and the stored accelerations are the same bits, ragged last quads and untouched bodies outside the
+    shard included; the owned bodies also equal the oracle's Euler update of the GPU's own accelerations."""
+    b = O.init_disc(n, seed=n)
+    kw = {"ref_compat": False}                              # (with it the last N % 8 bodies would not be targets at all)
+    if shard is not None:
+        kw["shard"] = shard
+    got = []
+    for scalar in (False, True):
+        if scalar:
+            monkeypatch.setenv("NBODY_INTEGRATE_SCALAR", "1")
+        got.append(run_gpu(nb, b, nsteps=1, **kw))
+    monkeypatch.delenv("NBODY_INTEGRATE_SCALAR")
+    (ax, ay, st, _), (bx, by, su, _) = got
+    assert np.array_equal(ax, bx) and np.array_equal(ay, by)
+    for k in ("posX", "posY", "velX", "velY"):
+        assert np.array_equal(st[k], su[k]), k
+    beg, cnt = (0, n) if shard is None else shard
+    own = np.zeros(n, bool); own[beg:beg + cnt] = True
+    for k in ("posX", "posY", "velX", "velY"):
+        assert np.array_equal(st[k][~own], getattr(b, k)[~own]), k
+    dt = np.float32(0.05)
+    fma = lambda a, c, d: (a.astype(np.float64) * np.float64(c) + d.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(st["posX"][own], fma(b.velX[own], dt, b.posX[own]))
+    assert np.array_equal(st["velY"][own], fma(ay[own], dt, b.velY[own]))
+
+
 def test_profile_counters(nb, O):
     b = O.init_disc(8192, seed=1)
     with nb.NBodySim(b.n, useBarnesHut=False) as sim:
