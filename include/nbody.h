@@ -45,11 +45,12 @@ typedef struct nbody_config {
     float   dt;              /* dt                                                               */
     float   theta;           /* theta                                                            */
     int32_t use_barnes_hut;  /* useBarnesHut: 0 = naive O(N^2) (benchmark.cpp:405), 1 = BH (:354).  BH limits: num_bodies
-                                <= 2^28 - 64 (32-bit node indices; NBODY_ERR_INVALID beyond).  The walk masks a target's
-                                own leaf by comparing INTEGER body indices; the reference compares them as floats
-                                (benchmark.cpp:197-198, 233-235), which is the same thing up to index 2^24 (every BASELINE
-                                configuration) and beyond that also masks the odd-indexed neighbour that rounds to the
-                                same float — a reference artefact that is not reproduced                           */
+                                <= 2^28 - 64 (32-bit node indices; NBODY_ERR_INVALID beyond).  The reference masks a target's
+                                own leaf by comparing body indices as FLOATS (benchmark.cpp:197-198, 233-235): the integer
+                                comparison up to index 2^24 (every BASELINE configuration); with more bodies than that a
+                                target also skips the neighbours whose index rounds to the same float.  ref_compat >= 1
+                                reproduces it (a second instantiation of the walk kernels, picked when num_bodies > 2^24;
+                                tests/test_gpu_bh_fullsize.py); ref_compat = 0 compares integers                           */
     int32_t use_parallel;    /* useParallel: in the BH branch 0 means "build tree, do nothing"
                                 (benchmark.cpp:359); ignored by the naive branch, as in the reference */
     int32_t ref_compat;      /* 1: reproduce benchmark.cpp's quirks — bodies with index >= N-N%8 are never targets

@@ -1545,7 +1545,11 @@ inline int bh_walk_groups_per_wave(int targets)
 __device__ __forceinline__ unsigned long long bh_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ bool bh_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
-template <bool kFast>
+// kFloatSelf: the reference's self-mask as it is written, on FLOAT indices (benchmark.cpp:197-198, 233-235).  Up to index
+// 2^24 that is the integer comparison; beyond it a target also skips the leaves of the neighbours whose index rounds to
+// the same float (above 2^24 every odd index rounds onto a multiple of 4).  The host picks it for ref_compat >= 1 and
+// more than 2^24 bodies; one v_cvt_f32_i32 per accepted node, which is why it is not the only form.
+template <bool kFast, bool kFloatSelf>
 __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
 {
 #pragma clang fp contract(off)   // every fma below is explicit: lanes reproduce oracle_bh_accel() bit for bit
@@ -1563,6 +1567,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     const int pc = live ? pos : w.i_end - 1;
     const int i = w.order ? w.order[pc] : pc;
     const float xi = w.px[i], yi = w.py[i], ri = w.radius[i];
+    [[maybe_unused]] const float fi = (float)i;
     const int grp_shift = (tid & 63) & ~7;                      // first lane of this group inside the wave
     const float eps = 1e-6f, soft2 = 0.001f * 0.001f;
     const float vote_margin = 4e-6f * w.theta;
@@ -1627,7 +1632,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
                         f = a.z / __builtin_fmaf(sd, sd, soft2);
                         inv = 1.0f / (d + eps);
                     }
-                    const bool self = b.y == i;                 // :197-198
+                    const bool self = kFloatSelf ? (float)b.y == fi : b.y == i;     // :197-198
                     ax = ax + (self ? 0.0f : (dx * inv) * f);
                     ay = ay + (self ? 0.0f : (dy * inv) * f);
                 } else {
@@ -1785,7 +1790,7 @@ __device__ __forceinline__ void bh_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool kFast>
+template <bool kFast, bool kFloatSelf>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBODY_QUAD_WAVES, 8))) void bh_walk_quad_kernel(const BhWalkArgs w)
 {
 #pragma clang fp contract(off)
@@ -1800,6 +1805,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBODY_QUAD_
     const int pc = live ? pos : w.i_end - 1;
     const int i = w.order ? w.order[pc] : pc;
     const float xi = w.px[i], yi = w.py[i], ri = w.radius[i];
+    [[maybe_unused]] const float fi = (float)i;
     const float eps = 1e-6f, soft2 = 0.001f * 0.001f;
     const float vote_margin = 4e-6f * w.theta;
     const unsigned long long below_me = (1ull << lane) - 1ull;
@@ -1914,7 +1920,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBODY_QUAD_
             f = a.z / __builtin_fmaf(sd, sd, soft2);
             inv = 1.0f / (d + eps);
         }
-        const bool self = b.y == i;                                    // :197-198
+        const bool self = kFloatSelf ? (float)b.y == fi : b.y == i;    // :197-198 (see bh_walk_kernel)
         tx = self ? 0.0f : (dx * inv) * f;
         ty = self ? 0.0f : (dy * inv) * f;
     };

@@ -420,16 +420,29 @@ int enqueue_bh_walk(nbody_ctx* ctx, int advance)
     const float tq = tn < 0.5f ? 0.5f : (tn > 1.0f ? 1.0f : tn);
     int quad_max = kBhQuadMinGroups + (int)((tq - 0.5f) * 2.0f * (float)(kBhQuadMaxGroups - kBhQuadMinGroups));
     if (const char* e = std::getenv("NBODY_BH_QUAD_MAX")) quad_max = std::atoi(e);              // developer/test switch
+    // benchmark.cpp:197-198 compares body indices as floats: beyond 2^24 that is not the integer comparison any more
+    const bool float_self = ctx->cfg.ref_compat != 0 && ctx->cfg.num_bodies > (1 << 24);
     if (groups <= quad_max) {
         w.lanes_used = 8;
-        if (ctx->cfg.bh_fast_math) bh_walk_quad_kernel<true><<<dim3(groups), dim3(256), 0, ctx->stream>>>(w);
-        else                       bh_walk_quad_kernel<false><<<dim3(groups), dim3(256), 0, ctx->stream>>>(w);
+        const dim3 grid(groups), blk(256);
+        if (float_self) {
+            if (ctx->cfg.bh_fast_math) bh_walk_quad_kernel<true, true><<<grid, blk, 0, ctx->stream>>>(w);
+            else                       bh_walk_quad_kernel<false, true><<<grid, blk, 0, ctx->stream>>>(w);
+        } else {
+            if (ctx->cfg.bh_fast_math) bh_walk_quad_kernel<true, false><<<grid, blk, 0, ctx->stream>>>(w);
+            else                       bh_walk_quad_kernel<false, false><<<grid, blk, 0, ctx->stream>>>(w);
+        }
     } else {
         w.lanes_used = 8 * bh_walk_groups_per_wave(nt);
         const int per_block = (kBhBlock / 64) * w.lanes_used;      // targets per workgroup
         const dim3 grid((nt + per_block - 1) / per_block), blk(kBhBlock);
-        if (ctx->cfg.bh_fast_math) bh_walk_kernel<true><<<grid, blk, 0, ctx->stream>>>(w);
-        else                       bh_walk_kernel<false><<<grid, blk, 0, ctx->stream>>>(w);
+        if (float_self) {
+            if (ctx->cfg.bh_fast_math) bh_walk_kernel<true, true><<<grid, blk, 0, ctx->stream>>>(w);
+            else                       bh_walk_kernel<false, true><<<grid, blk, 0, ctx->stream>>>(w);
+        } else {
+            if (ctx->cfg.bh_fast_math) bh_walk_kernel<true, false><<<grid, blk, 0, ctx->stream>>>(w);
+            else                       bh_walk_kernel<false, false><<<grid, blk, 0, ctx->stream>>>(w);
+        }
     }
     HIP_TRY(hipGetLastError());
     return profile_end(ctx, 0, ep);

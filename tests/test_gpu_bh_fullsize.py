@@ -164,3 +164,47 @@ def test_lattice_points_in_a_large_disc_equal_the_oracle(nb, O, n, spread_mode):
     O.lib().oracle_bh_accel(ot.h, nt, b.posX, b.posY, b.radius, 1.0, 0, 8, ox, oy, oc)
     assert cnt == dict(visits=int(oc[0]), accepts=int(oc[1]))
     assert np.array_equal(ax[:nt], ox[:nt].astype(np.float32)) and np.array_equal(ay[:nt], oy[:nt].astype(np.float32))
+
+
+def test_float_self_mask_beyond_index_2_24_equals_the_oracle(nb, O):
+    """benchmark.cpp:197-198 masks a target's own leaf by comparing body indices AS FLOATS.  Beyond index 2^24 odd
+    indices round onto multiples of 4, so target 2^24 + 1 also skips the leaf of body 2^24 (and vice versa): a reference
+    artefact that ref_compat >= 1 reproduces (bh_walk_kernel<., true>) once there are more than 2^24 bodies.  2^24 + 2048
+    bodies, the last 2048 in a tight cluster so that they meet each other as leaves; their accelerations and the walk's
+    counters equal the oracle's (which compares floats, as the reference does) bit for bit, and the integer comparison
+    of ref_compat = 0 gives different sums for exactly the targets that share their float with a neighbour."""
+    base, extra = 1 << 24, 2048
+    n = base + extra
+    b = O.init_disc(n, seed=99)
+    rng = np.random.default_rng(77)
+    b.posX[base:] = (100.0 + rng.uniform(-2.0, 2.0, extra)).astype(np.float32)
+    b.posY[base:] = (-50.0 + rng.uniform(-2.0, 2.0, extra)).astype(np.float32)
+    # 1.7e7 float positions in this disc hold an exactly coincident pair for about every other seed (2024 and 7 do), and
+    # on those the reference — and the oracle that follows it — recurses until the stack ends: check before building
+    site = (b.posX.view(np.uint32).astype(np.uint64) << np.uint64(32)) | b.posY.view(np.uint32).astype(np.uint64)
+    assert len(np.unique(site)) == n
+    got = {}
+    for compat in (1, 0):
+        with nb.NBodySim(n, theta=1.0, useBarnesHut=True, shard=(base, extra), ref_compat=compat) as sim:
+            sim.upload(*b.arrays())
+            sim.compute_accel().sync()
+            ax, ay = sim.accel()
+            sim.bh_tree(max_nodes=1)
+            got[compat] = (ax[base:].copy(), ay[base:].copy(), sim.bh_counters(), sim.bh_nodes_total)
+    ot = O.Tree(n).build(b, 400.0)
+    assert got[1][3] == ot.nodes_used
+    order = np.arange(base, n, dtype=np.int32)
+    ox = np.zeros(n); oy = np.zeros(n); oc = np.zeros(2, np.int64)
+    gv = np.zeros(extra // 8, np.int32); ga = np.zeros(extra // 8, np.int32)
+    O.lib().oracle_bh_accel_ordered(ot.h, extra, b.posX, b.posY, b.radius, 1.0, order, ox, oy, oc, gv, ga)
+    ax, ay, cnt, _ = got[1]
+    assert cnt == dict(visits=int(oc[0]), accepts=int(oc[1]))
+    assert np.array_equal(ax, ox[base:].astype(np.float32)) and np.array_equal(ay, oy[base:].astype(np.float32))
+    # the integer comparison: same votes, and other sums exactly where float(index) is shared with a neighbour
+    ix, iy, icnt, _ = got[0]
+    assert icnt == cnt
+    idx = np.arange(base, n)
+    shared = (idx % 4 != 2)                      # 4m-1, 4m, 4m+1 all round to 4m; 4m+2 is a float of its own
+    differs = (ix != ax) | (iy != ay)
+    assert not differs[~shared].any()
+    assert differs[shared].mean() > 0.75         # (8k + 7 shares its float with 8k + 8 and 8k + 9 only: another group, whose leaves it need not reach)
