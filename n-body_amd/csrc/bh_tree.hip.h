@@ -1549,14 +1549,20 @@ __device__ __forceinline__ bool bh_any(bool p) { return __builtin_amdgcn_ballot_
 // 2^24 that is the integer comparison; beyond it a target also skips the leaves of the neighbours whose index rounds to
 // the same float (above 2^24 every odd index rounds onto a multiple of 4).  The host picks it for ref_compat >= 1 and
 // more than 2^24 bodies; one v_cvt_f32_i32 per accepted node, which is why it is not the only form.
-template <bool kFast, bool kFloatSelf>
+#ifndef NBODY_WALK_SCALAR_VOTE
+#define NBODY_WALK_SCALAR_VOTE 1
+#endif
+// kOffs32: the tree's records are reached as base + 32-bit byte offset (the scalar-base addressing form: one shift per
+// record instead of a sign extension, a 64-bit shift-add and the register-pair copies around it).  The host picks it
+// while 16 B x (nodes the pool can hold) < 2^32, i.e. up to ~3.3e7 bodies.
+template <bool kFast, bool kFloatSelf, bool kOffs32>
 __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
 {
 #pragma clang fp contract(off)   // every fma below is explicit: lanes reproduce oracle_bh_accel() bit for bit
     // One stack column per GROUP of 8 lanes.  All 8 lanes of a group hold the same (node, sp) and execute the same
     // pushes/pops, so each lane writes the value it will later read back itself (same address, same value): no
     // cross-lane ordering is needed and 4.3 KB of LDS per workgroup leaves room for 8 waves per SIMD.
-    __shared__ int stack[kBhStackDepth][kBhBlock / 8];
+    __shared__ int stack[kBhStackDepth + 1][kBhBlock / 8];       // row 0 is never an entry: entry k lives in row k
     __shared__ unsigned long long red[3][kBhBlock / 64];
     const int tid = threadIdx.x;
     // wave v of the grid walks groups [v*G, (v+1)*G), G = lanes_used/8, on its first lanes_used lanes
@@ -1566,94 +1572,125 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     const bool live = lane < w.lanes_used && pos < w.i_end;
     const int pc = live ? pos : w.i_end - 1;
     const int i = w.order ? w.order[pc] : pc;
-    const float xi = w.px[i], yi = w.py[i], ri = w.radius[i];
+    const float xi = w.px[i], yi = w.py[i], ri = __builtin_canonicalizef(w.radius[i]);
     [[maybe_unused]] const float fi = (float)i;
     const int grp_shift = (tid & 63) & ~7;                      // first lane of this group inside the wave
     const float eps = 1e-6f, soft2 = 0.001f * 0.001f;
     const float vote_margin = 4e-6f * w.theta;
+    auto rec_a = [&](int nd) -> float4 {
+        if constexpr (kOffs32) return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w.A) + ((unsigned)nd << 4));
+        else return w.A[nd];
+    };
+    auto rec_b = [&](int nd) -> int2 {
+        if constexpr (kOffs32) return *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(w.B) + ((unsigned)nd << 3));
+        else return w.B[nd];
+    };
     float ax = 0.0f, ay = 0.0f;
     unsigned visits = 0, accepts = 0;
 
     // is any lane of my group a real target?
     const unsigned long long live_mask = bh_ballot(live);
-    int active = ((live_mask >> grp_shift) & 0xFFull) != 0 ? 1 : 0;   // an int on purpose: see bh_ballot
-    int node = 0, sp = 0;
-    float4 a = w.A[0];
-    int2 b = w.B[0];
+    // A finished group has node = -1: the loop's vote and the `if` below are one fresh comparison (see bh_ballot).
+    int node = ((live_mask >> grp_shift) & 0xFFull) != 0 ? 0 : -1, sp = 0;
+    stack[0][tid >> 3] = -1;                                    // (every lane of a group writes its group's column: no barrier)
     unsigned iters = 0;
+    // dx, dy, inv, f mean something only in an iteration that sets `take`.  They are declared out here so that on every
+    // other path they simply keep what they held (a value of their own per iteration would be given a 0 on every path that
+    // does not compute it: a register move per variable and nesting level); the select after the region drops them.
+    float dx = 0.0f, dy = 0.0f, inv = 0.0f, f = 0.0f;
     // (Tried, round 3: a per-lane `while (active)` loop, finished groups masked off by the hardware instead of by the
-    // `if (active)` below.  It removes the ~10 register copies per iteration that the compiler makes around the divergent
+    // `if` below.  It removes the ~10 register copies per iteration that the compiler makes around the divergent
     // region, and is SLOWER: walk 2.07 against 1.99 ms at N = 10^6, 0.46 against 0.385 at 65 536 — same-box A/B.)
-    while (bh_ballot(active != 0) != 0ull) {
+    // the groups still walking, as a lane mask: voted once per iteration, at its end, and handed back to the lanes as the
+    // condition of the next one (a second comparison of `node` saved)
+    unsigned long long walking = bh_ballot(node >= 0), not_root = 0ull;
+    while (walking != 0ull) {
         ++iters;
-        if (active) {
-            // (Tried: requesting the records of both likely successors — next sibling and last child — before this
-            // node's arithmetic.  Same-box A/B: no gain at N = 10^4..65 536, 28 % slower at N = 10^6; not kept.
-            // Tried: the whole body as straight-line predicated code (selects instead of nested branches): 110 ->
-            // 75 instructions per iteration, but the divisions then run for every group in every iteration:
-            // +8 % at N = 10^6 (IEEE) / +4 % (fast math), -14 % at N = 10^4; not kept.  Tried again once the node
-            // kernel had shrunk to exact_core.hip.h's 26 instructions: 2.17 against 2.03 ms at N = 10^6; not kept.)
-            const bool more_siblings = node != 0 && ((node - 1) & 3) != 0;
+        bool take = false;
+        if (__builtin_amdgcn_inverse_ballot_w64(walking)) {
+            // The scalar unit issues one instruction per 4 cycles and SIMD, like the vector unit (tools/ubench_walk.hip), and
+            // every level of divergent branching is ~5 scalar instructions of mask bookkeeping.  So only the node kernel
+            // — the long, often skipped part — sits in a branch; the vote is taken on every node (an empty one's is
+            // dropped) and the next node comes out of selects.
             ++visits;
-            bool open = false;
-            if (a.z != 0.0f) {                                  // benchmark.cpp:248
-                const float dx = a.x - xi, dy = a.y - yi;       // :254-255
-                const float d2 = __builtin_fmaf(dx, dx, dy * dy);
-                // The vote is a boolean, so both modes take it with the hardware's 1-ulp sqrt/rcp (3 instructions instead
-                // of the ~30 of a correctly rounded sqrt and division) unless the ratio is within 4e-6 (relative, > 10x
-                // its error bound) of theta; then the wave redoes the node with the IEEE expressions of
-                // benchmark.cpp:256-262.  Same decisions as the oracle either way (the counters are compared).
-                float d = __builtin_amdgcn_sqrtf(d2);
-                float inv = __builtin_amdgcn_rcpf(d + eps);
-                const float q = a.w * inv;
-                bool far = q < w.theta;
-                if (bh_any(__builtin_fabsf(q - w.theta) <= vote_margin))              // rare: ~1e-4 of the waves' visits
-                    far = (a.w / (__builtin_sqrtf(d2) + eps)) < w.theta;
-                const unsigned long long fm = bh_ballot(far) | ~live_mask;      // (= ballot(far || !live), one vote on a fresh compare)
-                const bool all_far = ((fm >> grp_shift) & 0xFFull) == 0xFFull;
-                if (b.x < 0 || all_far) {                       // :266 leaf or every lane far
-                    ++accepts;
-                    // computeForce_kernel, benchmark.cpp:188-225: the accepted term is computed in IEEE arithmetic
-                    // (correctly rounded sqrt and divisions) unless bh_fast_math asked for the hardware's
-                    // (IEEE: the same correctly rounded results from exact_core.hip.h's shorter sequences when every
-                    // accepting lane's d^2 is in their range — all but the self and far-escaped cases —, else hipcc's)
-                    float f;
-                    if constexpr (kFast) {
-                        const float sd = __builtin_fmaxf(d, ri);    // clamp radius is the TARGET's only (:201-202)
-                        f = a.z * __builtin_amdgcn_rcpf(__builtin_fmaf(sd, sd, soft2));
-                    } else if (w.exact_core && bh_ballot(!(d2 >= kCoreD2Min && d2 <= kCoreD2Max)) == 0ull) {
-                        d = core_sqrt_rn(d2, d);                                    // :193-194
-                        const float sd = __builtin_fmaxf(d, ri);
-                        f = core_div_rn(a.z, __builtin_fmaf(sd, sd, soft2));        // :203-209
-                        inv = core_rcp_rn_seeded(d + eps, inv);                     // :212-213, from the vote's v_rcp
-                    } else {
-                        d = __builtin_sqrtf(d2);
-                        const float sd = __builtin_fmaxf(d, ri);
-                        f = a.z / __builtin_fmaf(sd, sd, soft2);
-                        inv = 1.0f / (d + eps);
-                    }
-                    const bool self = kFloatSelf ? (float)b.y == fi : b.y == i;     // :197-198
-                    ax = ax + (self ? 0.0f : (dx * inv) * f);
-                    ay = ay + (self ? 0.0f : (dy * inv) * f);
+            // the node's records are requested here, not at the end of the previous iteration: a finished group (node -1)
+            // then never forms an address, at the price of ~10 instructions of overlap out of several hundred cycles
+            const float4 a = rec_a(node);
+            const int2 b = rec_b(node);
+            const int top = stack[sp][tid >> 3];                // the sibling to resume at if this subtree ends here (row 0: -1)
+            dx = a.x - xi; dy = a.y - yi;                       // benchmark.cpp:254-255
+            const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+            // The vote is a boolean, so both modes take it with the hardware's 1-ulp sqrt/rcp (3 instructions instead
+            // of the ~30 of a correctly rounded sqrt and division) unless the ratio is within 4e-6 (relative, > 10x
+            // its error bound) of theta; then the wave redoes the node with the IEEE expressions of
+            // benchmark.cpp:256-262.  Same decisions as the oracle either way (the counters are compared).
+            float d = __builtin_amdgcn_sqrtf(d2);
+            inv = __builtin_amdgcn_rcpf(d + eps);
+            const float q = a.w * inv;
+            bool far = q < w.theta;
+            if (bh_any(__builtin_fabsf(q - w.theta) <= vote_margin))              // rare: ~1e-4 of the waves' visits
+                far = (a.w / (__builtin_sqrtf(d2) + eps)) < w.theta;
+            // From here on the decisions are LANE MASKS combined on the scalar unit and handed back to the lanes as
+            // conditions (inverse ballot): written as bools, the compiler turns the same logic into 0/1 registers.
+            unsigned long long fm = bh_ballot(far) | ~live_mask;                // (= ballot(far || !live), one vote on a fresh compare)
+#if NBODY_WALK_SCALAR_VOTE
+            // "every lane of my group is far (or not a target)": fold each byte of the vote onto its bit 0 and spread
+            // that bit back over the byte (12 scalar instructions)
+            fm &= fm >> 1; fm &= fm >> 2; fm &= fm >> 4;
+            fm &= 0x0101010101010101ull;
+            fm = (fm << 8) - fm;
+#else
+            fm = bh_ballot(((unsigned)(fm >> grp_shift) & 0xFFu) == 0xFFu);     // the same per lane: shift, and, compare
+#endif
+            const unsigned long long massive_m = bh_ballot(a.z != 0.0f);        // benchmark.cpp:248: an empty node is neither
+            const unsigned long long leaf_m = bh_ballot(b.x < 0);               //                    accepted nor opened
+            const unsigned long long accept_m = massive_m & (leaf_m | fm);      // :266 leaf or every lane far
+            const unsigned long long open_m = massive_m & ~accept_m;
+            const bool accept = __builtin_amdgcn_inverse_ballot_w64(accept_m);
+            if (accept) {
+                ++accepts;
+                // computeForce_kernel, benchmark.cpp:188-225: the accepted term is computed in IEEE arithmetic
+                // (correctly rounded sqrt and divisions) unless bh_fast_math asked for the hardware's
+                // (IEEE: the same correctly rounded results from exact_core.hip.h's shorter sequences when every
+                // accepting lane's d^2 is in their range — all but the self and far-escaped cases —, else hipcc's)
+                if constexpr (kFast) {
+                    const float sd = __builtin_fmaxf(d, ri);    // clamp radius is the TARGET's only (:201-202)
+                    f = a.z * __builtin_amdgcn_rcpf(__builtin_fmaf(sd, sd, soft2));
+                } else if (w.exact_core && bh_ballot(!(d2 >= kCoreD2Min && d2 <= kCoreD2Max)) == 0ull) {
+                    d = core_sqrt_rn(d2, d);                                    // :193-194
+                    // fmaxf() would first canonicalize both operands (two more v_max): d is a number here and ri was
+                    // canonicalized when it was loaded, so the bare instruction gives fmaxf's result
+                    float sd;
+                    asm("v_max_f32 %0, %1, %2" : "=v"(sd) : "v"(d), "v"(ri));
+                    f = core_div_rn(a.z, __builtin_fmaf(sd, sd, soft2));        // :203-209
+                    inv = core_rcp_rn_seeded(d + eps, inv);                     // :212-213, from the vote's v_rcp
                 } else {
-                    open = true;
+                    d = __builtin_sqrtf(d2);
+                    const float sd = __builtin_fmaxf(d, ri);
+                    f = a.z / __builtin_fmaf(sd, sd, soft2);
+                    inv = 1.0f / (d + eps);
                 }
+                take = kFloatSelf ? (float)b.y != fi : b.y != i;                // :197-198: not the target's own leaf
             }
-            if (open) {
-                if (more_siblings) stack[sp++][tid >> 3] = node - 1;
-                node = b.x + 3;                                 // children pushed 0..3, popped 3..0 (:272-274, :244)
-                a = w.A[node]; b = w.B[node];
-            } else if (more_siblings) {
-                node = node - 1;
-                a = w.A[node]; b = w.B[node];
-            } else if (sp > 0) {
-                node = stack[--sp][tid >> 3];
-                a = w.A[node];
-                b = w.B[node];
-            } else {
-                active = 0;
-            }
+            // Next node.  Children are pushed 0..3 and popped 3..0 (:272-274, :244): an opened node continues at its
+            // child 3 and leaves its own next sibling on the stack; otherwise the next sibling, else the stack's top,
+            // and the top of the empty stack is -1: the group is done.  The sibling is written to the free slot above
+            // the top in any case and stays there only if sp moves.
+            const unsigned long long more_m = bh_ballot(((node - 1) & 3) != 0) & not_root;    // (the root has no siblings)
+            stack[sp + 1][tid >> 3] = node - 1;
+            const int next = __builtin_amdgcn_inverse_ballot_w64(open_m) ? b.x + 3 : node - 1;
+            node = __builtin_amdgcn_inverse_ballot_w64(open_m | more_m) ? next : top;   // (row 0 holds -1: popping the empty stack ends the group)
+            // sp += pushed; sp -= popped: add and subtract with carry-in from the masks
+            asm("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(sp) : "s"(open_m & more_m) : "vcc");
+            asm("v_subb_co_u32 %0, vcc, %0, %2, %1" : "+v"(sp) : "s"(~(open_m | more_m)), "v"(0) : "vcc");
         }
+        // (+0 leaves a sum as it is: the sums start at +0 and x + (-x) = +0, so none of them is ever -0)
+        // (dx and inv are always of one and the same visit, |dx * inv| <= 1: times a zero f that is a zero)
+        const float fs = take ? f : 0.0f;
+        ax = ax + (dx * inv) * fs;
+        ay = ay + (dy * inv) * fs;
+        walking = bh_ballot(node >= 0);
+        not_root = ~0ull;
     }
     // The reference integrates each group right after its walk, in place (benchmark.cpp:382-401): that is race-free
     // because the tree holds COPIES of the positions (leaf records), and it is race-free here for the same reason —

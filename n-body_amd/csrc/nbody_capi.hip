@@ -436,12 +436,19 @@ int enqueue_bh_walk(nbody_ctx* ctx, int advance)
         w.lanes_used = 8 * bh_walk_groups_per_wave(nt);
         const int per_block = (kBhBlock / 64) * w.lanes_used;      // targets per workgroup
         const dim3 grid((nt + per_block - 1) / per_block), blk(kBhBlock);
-        if (float_self) {
-            if (ctx->cfg.bh_fast_math) bh_walk_kernel<true, true><<<grid, blk, 0, ctx->stream>>>(w);
-            else                       bh_walk_kernel<false, true><<<grid, blk, 0, ctx->stream>>>(w);
-        } else {
-            if (ctx->cfg.bh_fast_math) bh_walk_kernel<true, false><<<grid, blk, 0, ctx->stream>>>(w);
-            else                       bh_walk_kernel<false, false><<<grid, blk, 0, ctx->stream>>>(w);
+        // 32-bit byte offsets into the node records while 16 B x pool capacity fits (see bh_walk_kernel).  That ends
+        // beyond 2^24 bodies, where the float self-mask is on: three of the four combinations exist.
+        const bool offs32 = (4ll * (2ll * ctx->cfg.num_bodies + 64) + 1) * 16 < (1ll << 32) && !std::getenv("NBODY_BH_WALK_OFFS64");
+        const bool fast = ctx->cfg.bh_fast_math != 0;
+        if (offs32 && !float_self) {
+            if (fast) bh_walk_kernel<true, false, true><<<grid, blk, 0, ctx->stream>>>(w);
+            else      bh_walk_kernel<false, false, true><<<grid, blk, 0, ctx->stream>>>(w);
+        } else if (offs32) {
+            if (fast) bh_walk_kernel<true, true, true><<<grid, blk, 0, ctx->stream>>>(w);
+            else      bh_walk_kernel<false, true, true><<<grid, blk, 0, ctx->stream>>>(w);
+        } else {         // (the float comparison is the integer one below 2^24 bodies: the developer switch lands here too)
+            if (fast) bh_walk_kernel<true, true, false><<<grid, blk, 0, ctx->stream>>>(w);
+            else      bh_walk_kernel<false, true, false><<<grid, blk, 0, ctx->stream>>>(w);
         }
     }
     HIP_TRY(hipGetLastError());
