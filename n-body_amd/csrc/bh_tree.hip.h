@@ -1577,8 +1577,10 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     const int grp_shift = (tid & 63) & ~7;                      // first lane of this group inside the wave
     const float eps = 1e-6f, soft2 = 0.001f * 0.001f;
     const float vote_margin = 4e-6f * w.theta;
+    // (8 * node, and that plus itself: a shift and an add — an add issues in half a shift's time, tools/ubench_walk.hip)
     auto rec_a = [&](int nd) -> float4 {
-        if constexpr (kOffs32) return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w.A) + ((unsigned)nd << 4));
+        const unsigned o8 = (unsigned)nd << 3;
+        if constexpr (kOffs32) return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w.A) + (o8 + o8));
         else return w.A[nd];
     };
     auto rec_b = [&](int nd) -> int2 {
@@ -1606,7 +1608,6 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     unsigned long long walking = bh_ballot(node >= 0), not_root = 0ull;
     while (walking != 0ull) {
         ++iters;
-        bool take = false;
         if (__builtin_amdgcn_inverse_ballot_w64(walking)) {
             // The scalar unit issues one instruction per 4 cycles and SIMD, like the vector unit (tools/ubench_walk.hip), and
             // every level of divergent branching is ~5 scalar instructions of mask bookkeeping.  So only the node kernel
@@ -1647,6 +1648,8 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
             const unsigned long long accept_m = massive_m & (leaf_m | fm);      // :266 leaf or every lane far
             const unsigned long long open_m = massive_m & ~accept_m;
             const bool accept = __builtin_amdgcn_inverse_ballot_w64(accept_m);
+            // :197-198: an accepted node adds its term unless it is the target's own leaf
+            const unsigned long long take_m = accept_m & (kFloatSelf ? bh_ballot((float)b.y != fi) : bh_ballot(b.y != i));
             if (accept) {
                 ++accepts;
                 // computeForce_kernel, benchmark.cpp:188-225: the accepted term is computed in IEEE arithmetic
@@ -1670,7 +1673,6 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
                     f = a.z / __builtin_fmaf(sd, sd, soft2);
                     inv = 1.0f / (d + eps);
                 }
-                take = kFloatSelf ? (float)b.y != fi : b.y != i;                // :197-198: not the target's own leaf
             }
             // Next node.  Children are pushed 0..3 and popped 3..0 (:272-274, :244): an opened node continues at its
             // child 3 and leaves its own next sibling on the stack; otherwise the next sibling, else the stack's top,
@@ -1683,12 +1685,12 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
             // sp += pushed; sp -= popped: add and subtract with carry-in from the masks
             asm("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(sp) : "s"(open_m & more_m) : "vcc");
             asm("v_subb_co_u32 %0, vcc, %0, %2, %1" : "+v"(sp) : "s"(~(open_m | more_m)), "v"(0) : "vcc");
+            // (+0 leaves a sum as it is: the sums start at +0 and x + (-x) = +0, so none of them is ever -0;
+            //  dx and inv are always of one and the same visit, |dx * inv| <= 1: times a zero f that is a zero)
+            const float fs = __builtin_amdgcn_inverse_ballot_w64(take_m) ? f : 0.0f;
+            ax = ax + (dx * inv) * fs;
+            ay = ay + (dy * inv) * fs;
         }
-        // (+0 leaves a sum as it is: the sums start at +0 and x + (-x) = +0, so none of them is ever -0)
-        // (dx and inv are always of one and the same visit, |dx * inv| <= 1: times a zero f that is a zero)
-        const float fs = take ? f : 0.0f;
-        ax = ax + (dx * inv) * fs;
-        ay = ay + (dy * inv) * fs;
         walking = bh_ballot(node >= 0);
         not_root = ~0ull;
     }
