@@ -1606,6 +1606,8 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     // the groups still walking, as a lane mask: voted once per iteration, at its end, and handed back to the lanes as the
     // condition of the next one (a second comparison of `node` saved)
     unsigned long long walking = bh_ballot(node >= 0), not_root = 0ull;
+    float4 a = rec_a(0);
+    int2 b = rec_b(0);
     while (walking != 0ull) {
         ++iters;
         if (__builtin_amdgcn_inverse_ballot_w64(walking)) {
@@ -1614,10 +1616,6 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
             // — the long, often skipped part — sits in a branch; the vote is taken on every node (an empty one's is
             // dropped) and the next node comes out of selects.
             ++visits;
-            // the node's records are requested here, not at the end of the previous iteration: a finished group (node -1)
-            // then never forms an address, at the price of ~10 instructions of overlap out of several hundred cycles
-            const float4 a = rec_a(node);
-            const int2 b = rec_b(node);
             const int top = stack[sp][tid >> 3];                // the sibling to resume at if this subtree ends here (row 0: -1)
             dx = a.x - xi; dy = a.y - yi;                       // benchmark.cpp:254-255
             const float d2 = __builtin_fmaf(dx, dx, dy * dy);
@@ -1650,30 +1648,6 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
             const bool accept = __builtin_amdgcn_inverse_ballot_w64(accept_m);
             // :197-198: an accepted node adds its term unless it is the target's own leaf
             const unsigned long long take_m = accept_m & (kFloatSelf ? bh_ballot((float)b.y != fi) : bh_ballot(b.y != i));
-            if (accept) {
-                ++accepts;
-                // computeForce_kernel, benchmark.cpp:188-225: the accepted term is computed in IEEE arithmetic
-                // (correctly rounded sqrt and divisions) unless bh_fast_math asked for the hardware's
-                // (IEEE: the same correctly rounded results from exact_core.hip.h's shorter sequences when every
-                // accepting lane's d^2 is in their range — all but the self and far-escaped cases —, else hipcc's)
-                if constexpr (kFast) {
-                    const float sd = __builtin_fmaxf(d, ri);    // clamp radius is the TARGET's only (:201-202)
-                    f = a.z * __builtin_amdgcn_rcpf(__builtin_fmaf(sd, sd, soft2));
-                } else if (w.exact_core && bh_ballot(!(d2 >= kCoreD2Min && d2 <= kCoreD2Max)) == 0ull) {
-                    d = core_sqrt_rn(d2, d);                                    // :193-194
-                    // fmaxf() would first canonicalize both operands (two more v_max): d is a number here and ri was
-                    // canonicalized when it was loaded, so the bare instruction gives fmaxf's result
-                    float sd;
-                    asm("v_max_f32 %0, %1, %2" : "=v"(sd) : "v"(d), "v"(ri));
-                    f = core_div_rn(a.z, __builtin_fmaf(sd, sd, soft2));        // :203-209
-                    inv = core_rcp_rn_seeded(d + eps, inv);                     // :212-213, from the vote's v_rcp
-                } else {
-                    d = __builtin_sqrtf(d2);
-                    const float sd = __builtin_fmaxf(d, ri);
-                    f = a.z / __builtin_fmaf(sd, sd, soft2);
-                    inv = 1.0f / (d + eps);
-                }
-            }
             // Next node.  Children are pushed 0..3 and popped 3..0 (:272-274, :244): an opened node continues at its
             // child 3 and leaves its own next sibling on the stack; otherwise the next sibling, else the stack's top,
             // and the top of the empty stack is -1: the group is done.  The sibling is written to the free slot above
@@ -1685,6 +1659,39 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
             // sp += pushed; sp -= popped: add and subtract with carry-in from the masks
             asm("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(sp) : "s"(open_m & more_m) : "vcc");
             asm("v_subb_co_u32 %0, vcc, %0, %2, %1" : "+v"(sp) : "s"(~(open_m | more_m)), "v"(0) : "vcc");
+            // The next node's records are requested NOW, before this node's term is computed: the node kernel below —
+            // the longest dependent stretch of the iteration — runs while they travel.  It needs the mass of this node only.
+            // (A finished group asks for the root again: cheaper than a branch around the loads.)
+            const float mass = a.z;
+            {
+                const int nd = node > 0 ? node : 0;
+                a = rec_a(nd);
+                b = rec_b(nd);
+            }
+            if (accept) {
+                ++accepts;
+                // computeForce_kernel, benchmark.cpp:188-225: the accepted term is computed in IEEE arithmetic
+                // (correctly rounded sqrt and divisions) unless bh_fast_math asked for the hardware's
+                // (IEEE: the same correctly rounded results from exact_core.hip.h's shorter sequences when every
+                // accepting lane's d^2 is in their range — all but the self and far-escaped cases —, else hipcc's)
+                if constexpr (kFast) {
+                    const float sd = __builtin_fmaxf(d, ri);    // clamp radius is the TARGET's only (:201-202)
+                    f = mass * __builtin_amdgcn_rcpf(__builtin_fmaf(sd, sd, soft2));
+                } else if (w.exact_core && bh_ballot(!(d2 >= kCoreD2Min && d2 <= kCoreD2Max)) == 0ull) {
+                    d = core_sqrt_rn(d2, d);                                    // :193-194
+                    // fmaxf() would first canonicalize both operands (two more v_max): d is a number here and ri was
+                    // canonicalized when it was loaded, so the bare instruction gives fmaxf's result
+                    float sd;
+                    asm("v_max_f32 %0, %1, %2" : "=v"(sd) : "v"(d), "v"(ri));
+                    f = core_div_rn(mass, __builtin_fmaf(sd, sd, soft2));       // :203-209
+                    inv = core_rcp_rn_seeded(d + eps, inv);                     // :212-213, from the vote's v_rcp
+                } else {
+                    d = __builtin_sqrtf(d2);
+                    const float sd = __builtin_fmaxf(d, ri);
+                    f = mass / __builtin_fmaf(sd, sd, soft2);
+                    inv = 1.0f / (d + eps);
+                }
+            }
             // (+0 leaves a sum as it is: the sums start at +0 and x + (-x) = +0, so none of them is ever -0;
             //  dx and inv are always of one and the same visit, |dx * inv| <= 1: times a zero f that is a zero)
             const float fs = __builtin_amdgcn_inverse_ballot_w64(take_m) ? f : 0.0f;
