@@ -1518,6 +1518,7 @@ struct BhWalkArgs {
     int* __restrict__ grp_accepts;   //           nodes accepted by this walk (parity hook, nbody_bh_group_counters)
     const int* __restrict__ order;   // bh_sorted: walk position -> body (the build's sorted order); nullptr: identity
     int exact_core;                  // 1: masses and radii are in the range exact_core.hip.h needs (checked at upload)
+    int done_node;                   // bh_walk_kernel: index of the pool's spare last record ("this group is done")
 };
 
 // Groups per wave.  8 (all 64 lanes) is the throughput shape.  With few groups the walk is a latency chain and the
@@ -1577,14 +1578,17 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     const int grp_shift = (tid & 63) & ~7;                      // first lane of this group inside the wave
     const float eps = 1e-6f, soft2 = 0.001f * 0.001f;
     const float vote_margin = 4e-6f * w.theta;
-    // (8 * node, and that plus itself: a shift and an add — an add issues in half a shift's time, tools/ubench_walk.hip)
+    // With kOffs32 the traversal variable `node` is 8 x the node index: the byte offset of the node's B record, half that
+    // of its A record (plain indices otherwise).  A finished group holds `done` = the pool's spare last record, never a
+    // node: a valid address, so the loads below need no guard.
+    constexpr int kSh = kOffs32 ? 3 : 0, kOne = 1 << kSh;
+    const int done = w.done_node << kSh;
     auto rec_a = [&](int nd) -> float4 {
-        const unsigned o8 = (unsigned)nd << 3;
-        if constexpr (kOffs32) return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w.A) + (o8 + o8));
+        if constexpr (kOffs32) return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w.A) + ((unsigned)nd << 1));
         else return w.A[nd];
     };
     auto rec_b = [&](int nd) -> int2 {
-        if constexpr (kOffs32) return *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(w.B) + ((unsigned)nd << 3));
+        if constexpr (kOffs32) return *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(w.B) + (unsigned)nd);
         else return w.B[nd];
     };
     float ax = 0.0f, ay = 0.0f;
@@ -1592,48 +1596,60 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
 
     // is any lane of my group a real target?
     const unsigned long long live_mask = bh_ballot(live);
-    // A finished group has node = -1: the loop's vote and the `if` below are one fresh comparison (see bh_ballot).
-    int node = ((live_mask >> grp_shift) & 0xFFull) != 0 ? 0 : -1, sp = 0;
-    stack[0][tid >> 3] = -1;                                    // (every lane of a group writes its group's column: no barrier)
+    int node = ((live_mask >> grp_shift) & 0xFFull) != 0 ? 0 : done, sp = 0;
+    stack[0][tid >> 3] = done;                               // (every lane of a group writes its group's column: no barrier)
     unsigned iters = 0;
-    // dx, dy, inv, f mean something only in an iteration that sets `take`.  They are declared out here so that on every
-    // other path they simply keep what they held (a value of their own per iteration would be given a 0 on every path that
-    // does not compute it: a register move per variable and nesting level); the select after the region drops them.
-    float dx = 0.0f, dy = 0.0f, inv = 0.0f, f = 0.0f;
+    // dx, dy and the packed pair res = {1 / (d + eps), f} mean something only in an iteration that takes the node's term.
+    // They are declared out here so that on every other path they simply keep what they held (a value of their own per
+    // iteration would be given a 0 on every path that does not compute it: a register move per variable and nesting
+    // level); the select after the node kernel drops them.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    float dx = 0.0f, dy = 0.0f;
+    f2 res = {0.0f, 0.0f};
+    f2 one_mass = {1.0f, 0.0f};                                  // the dividends of the node kernel's two divisions
+    const float theta_lo = w.theta - vote_margin, theta_hi = w.theta + vote_margin;
     // (Tried, round 3: a per-lane `while (active)` loop, finished groups masked off by the hardware instead of by the
     // `if` below.  It removes the ~10 register copies per iteration that the compiler makes around the divergent
     // region, and is SLOWER: walk 2.07 against 1.99 ms at N = 10^6, 0.46 against 0.385 at 65 536 — same-box A/B.)
-    // the groups still walking, as a lane mask: voted once per iteration, at its end, and handed back to the lanes as the
-    // condition of the next one (a second comparison of `node` saved)
-    unsigned long long walking = bh_ballot(node >= 0), not_root = 0ull;
+    //
+    // The loop below is bound by the NUMBER of vector instructions: rocprofv3 shows the vector unit busy in every cycle
+    // at 4.2 cycles per instruction, whatever their kind (profiles/r3_walk_pmc.txt), while the scalar unit — one
+    // instruction per 4 cycles and SIMD as well (tools/ubench_walk.hip) — has room.  Hence:
+    //  * decisions are LANE MASKS combined on the scalar unit and handed back to the lanes as conditions (inverse
+    //    ballot); written as bools, the compiler turns the same logic into 0/1 registers and compares;
+    //  * only the node kernel — long, and skipped by a third of the visits — sits in a branch: every level of divergent
+    //    branching costs ~5 scalar instructions of mask bookkeeping and a copy of every value live across it;
+    //  * the next node comes out of selects, and its records are requested before this node's term is computed;
+    //  * the groups still walking are voted once per iteration and the vote is the next iteration's condition.
+    unsigned long long walking = bh_ballot(node != done), not_root = 0ull;
     float4 a = rec_a(0);
     int2 b = rec_b(0);
     while (walking != 0ull) {
         ++iters;
         if (__builtin_amdgcn_inverse_ballot_w64(walking)) {
-            // The scalar unit issues one instruction per 4 cycles and SIMD, like the vector unit (tools/ubench_walk.hip), and
-            // every level of divergent branching is ~5 scalar instructions of mask bookkeeping.  So only the node kernel
-            // — the long, often skipped part — sits in a branch; the vote is taken on every node (an empty one's is
-            // dropped) and the next node comes out of selects.
             ++visits;
-            const int top = stack[sp][tid >> 3];                // the sibling to resume at if this subtree ends here (row 0: -1)
+            const int top = stack[sp][tid >> 3];                // the sibling to resume at if this subtree ends here (row 0: done)
             dx = a.x - xi; dy = a.y - yi;                       // benchmark.cpp:254-255
             const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+            // Below 2^-96 (a target's own leaf: 0) the squared distance changes nothing that follows: d + eps is eps
+            // and max(d, r)^2 + soft^2 is soft^2 or r^2 + soft^2 either way.  Clamped there, exact_core.hip.h's
+            // sequences cover it, and the wave does not fall back to the compiler's for every own leaf it meets.
+            float d2c;
+            asm("v_max_f32 %0, %1, %2" : "=v"(d2c) : "v"(d2), "v"(kCoreD2Min));      // (bare: d2 is a number or a quiet NaN)
             // The vote is a boolean, so both modes take it with the hardware's 1-ulp sqrt/rcp (3 instructions instead
             // of the ~30 of a correctly rounded sqrt and division) unless the ratio is within 4e-6 (relative, > 10x
-            // its error bound) of theta; then the wave redoes the node with the IEEE expressions of
-            // benchmark.cpp:256-262.  Same decisions as the oracle either way (the counters are compared).
-            float d = __builtin_amdgcn_sqrtf(d2);
-            inv = __builtin_amdgcn_rcpf(d + eps);
-            const float q = a.w * inv;
-            bool far = q < w.theta;
+            // its error bound) of theta — it lies on different sides of theta -+ that —; then the wave redoes the node
+            // with the IEEE expressions of benchmark.cpp:256-262.  Same decisions as the oracle either way (the
+            // counters are compared).
+            const float d_hw = __builtin_amdgcn_sqrtf(d2c);
+            const float inv_hw = __builtin_amdgcn_rcpf(d_hw + eps);
+            const float q = a.w * inv_hw;
+            unsigned long long fm = bh_ballot(q < theta_lo);
             // (Tried: __builtin_expect here and on the node kernel's range test below, which lays the common path out as
             // straight fall-through — two taken branches fewer per iteration: no gain, and 2.7 % slower with both.)
-            if (bh_any(__builtin_fabsf(q - w.theta) <= vote_margin))              // rare: ~1e-4 of the waves' visits
-                far = (a.w / (__builtin_sqrtf(d2) + eps)) < w.theta;
-            // From here on the decisions are LANE MASKS combined on the scalar unit and handed back to the lanes as
-            // conditions (inverse ballot): written as bools, the compiler turns the same logic into 0/1 registers.
-            unsigned long long fm = bh_ballot(far) | ~live_mask;                // (= ballot(far || !live), one vote on a fresh compare)
+            if (fm != bh_ballot(q < theta_hi))                                  // rare: ~1e-4 of the waves' visits
+                fm = bh_ballot((a.w / (__builtin_sqrtf(d2) + eps)) < w.theta);
+            fm |= ~live_mask;                                                   // far, or not a target
 #if NBODY_WALK_SCALAR_VOTE
             // "every lane of my group is far (or not a target)" on the scalar unit: s_wqm_b64 turns every 4 bits into
             // "any of them", or-ing the two halves of a byte gives "any of the 8" in its low half, x 17 copies that to
@@ -1648,60 +1664,56 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
             const unsigned long long leaf_m = bh_ballot(b.x < 0);               //                    accepted nor opened
             const unsigned long long accept_m = massive_m & (leaf_m | fm);      // :266 leaf or every lane far
             const unsigned long long open_m = massive_m & ~accept_m;
-            const bool accept = __builtin_amdgcn_inverse_ballot_w64(accept_m);
             // :197-198: an accepted node adds its term unless it is the target's own leaf
             const unsigned long long take_m = accept_m & (kFloatSelf ? bh_ballot((float)b.y != fi) : bh_ballot(b.y != i));
             // Next node.  Children are pushed 0..3 and popped 3..0 (:272-274, :244): an opened node continues at its
             // child 3 and leaves its own next sibling on the stack; otherwise the next sibling, else the stack's top,
-            // and the top of the empty stack is -1: the group is done.  The sibling is written to the free slot above
-            // the top in any case and stays there only if sp moves.
-            const unsigned long long more_m = bh_ballot(((node - 1) & 3) != 0) & not_root;    // (the root has no siblings)
-            stack[sp + 1][tid >> 3] = node - 1;
-            const int next = __builtin_amdgcn_inverse_ballot_w64(open_m) ? b.x + 3 : node - 1;
-            node = __builtin_amdgcn_inverse_ballot_w64(open_m | more_m) ? next : top;   // (row 0 holds -1: popping the empty stack ends the group)
+            // and the top of the empty stack is done: the group is done.  The sibling is written to the free slot
+            // above the top in any case and stays there only if sp moves.
+            const unsigned long long more_m = bh_ballot(((node - kOne) & (3 * kOne)) != 0) & not_root;    // (the root has no siblings)
+            stack[sp + 1][tid >> 3] = node - kOne;
+            const int next = __builtin_amdgcn_inverse_ballot_w64(open_m) ? (b.x << kSh) + 3 * kOne : node - kOne;
+            node = __builtin_amdgcn_inverse_ballot_w64(open_m | more_m) ? next : top;
             // sp += pushed; sp -= popped: add and subtract with carry-in from the masks
             asm("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(sp) : "s"(open_m & more_m) : "vcc");
             asm("v_subb_co_u32 %0, vcc, %0, %2, %1" : "+v"(sp) : "s"(~(open_m | more_m)), "v"(0) : "vcc");
             // The next node's records are requested NOW, before this node's term is computed: the node kernel below —
             // the longest dependent stretch of the iteration — runs while they travel.  It needs the mass of this node only.
-            // (A finished group asks for the root again: cheaper than a branch around the loads.)
-            const float mass = a.z;
-            {
-                const int nd = node > 0 ? node : 0;
-                a = rec_a(nd);
-                b = rec_b(nd);
-            }
-            if (accept) {
+            one_mass.y = a.z;
+            a = rec_a(node);
+            b = rec_b(node);
+            if (__builtin_amdgcn_inverse_ballot_w64(accept_m)) {
                 ++accepts;
                 // computeForce_kernel, benchmark.cpp:188-225: the accepted term is computed in IEEE arithmetic
                 // (correctly rounded sqrt and divisions) unless bh_fast_math asked for the hardware's
                 // (IEEE: the same correctly rounded results from exact_core.hip.h's shorter sequences when every
-                // accepting lane's d^2 is in their range — all but the self and far-escaped cases —, else hipcc's)
+                // accepting lane's d^2 is in their range — all but the far-escaped cases —, else hipcc's)
                 if constexpr (kFast) {
-                    const float sd = __builtin_fmaxf(d, ri);    // clamp radius is the TARGET's only (:201-202)
-                    f = mass * __builtin_amdgcn_rcpf(__builtin_fmaf(sd, sd, soft2));
-                } else if (w.exact_core && bh_ballot(!(d2 >= kCoreD2Min && d2 <= kCoreD2Max)) == 0ull) {
-                    d = core_sqrt_rn(d2, d);                                    // :193-194
+                    const float sd = __builtin_fmaxf(d_hw, ri);   // clamp radius is the TARGET's only (:201-202)
+                    res = f2{inv_hw, one_mass.y * __builtin_amdgcn_rcpf(__builtin_fmaf(sd, sd, soft2))};
+                } else if (w.exact_core && bh_ballot(!(d2c <= kCoreD2Max)) == 0ull) {
+                    const float d = core_sqrt_rn(d2c, d_hw);                    // :193-194
                     // fmaxf() would first canonicalize both operands (two more v_max): d is a number here and ri was
                     // canonicalized when it was loaded, so the bare instruction gives fmaxf's result
                     float sd;
                     asm("v_max_f32 %0, %1, %2" : "=v"(sd) : "v"(d), "v"(ri));
-                    f = core_div_rn(mass, __builtin_fmaf(sd, sd, soft2));       // :203-209
-                    inv = core_rcp_rn_seeded(d + eps, inv);                     // :212-213, from the vote's v_rcp
+                    // {1 / (d + eps), mass / (sd^2 + soft^2)}, :212-213 and :203-209, both correctly rounded, as ONE
+                    // packed sequence; the first starts its Newton step from the vote's v_rcp_f32 of the 1-ulp distance
+                    const float den = __builtin_fmaf(sd, sd, soft2);
+                    res = core_div2_rn(one_mass, f2{d + eps, den}, f2{inv_hw, __builtin_amdgcn_rcpf(den)});
                 } else {
-                    d = __builtin_sqrtf(d2);
+                    const float d = __builtin_sqrtf(d2);
                     const float sd = __builtin_fmaxf(d, ri);
-                    f = mass / __builtin_fmaf(sd, sd, soft2);
-                    inv = 1.0f / (d + eps);
+                    res = f2{1.0f / (d + eps), one_mass.y / __builtin_fmaf(sd, sd, soft2)};
                 }
             }
             // (+0 leaves a sum as it is: the sums start at +0 and x + (-x) = +0, so none of them is ever -0;
-            //  dx and inv are always of one and the same visit, |dx * inv| <= 1: times a zero f that is a zero)
-            const float fs = __builtin_amdgcn_inverse_ballot_w64(take_m) ? f : 0.0f;
-            ax = ax + (dx * inv) * fs;
-            ay = ay + (dy * inv) * fs;
+            //  dx and 1 / (d + eps) are always of one and the same visit, their product at most 1: times a zero f, a zero)
+            const float fs = __builtin_amdgcn_inverse_ballot_w64(take_m) ? res.y : 0.0f;
+            ax = ax + (dx * res.x) * fs;
+            ay = ay + (dy * res.x) * fs;
         }
-        walking = bh_ballot(node >= 0);
+        walking = bh_ballot(node != done);
         not_root = ~0ull;
     }
     // The reference integrates each group right after its walk, in place (benchmark.cpp:382-401): that is race-free

@@ -85,4 +85,21 @@ __device__ __forceinline__ float core_rcp_rn_seeded(float b, float r0)
     return __builtin_fmaf(t, r, q);
 }
 
+// {a.x / b.x, a.y / b.y}, both correctly rounded, as one packed sequence: core_div_rn on two lanes, each starting from
+// the reciprocal estimate r0 it is given — v_rcp_f32(b), or for core_rcp_rn_seeded's case (a.x = 1) the estimate that
+// function documents (1 * r is r: the same values as its q = r).
+typedef float core_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ core_f2 core_div2_rn(core_f2 a, core_f2 b, core_f2 r0)
+{
+#pragma clang fp contract(off)
+    const core_f2 one = {1.0f, 1.0f};
+    const core_f2 e = __builtin_elementwise_fma(-b, r0, one);
+    const core_f2 r = __builtin_elementwise_fma(e, r0, r0);
+    core_f2 q = a * r;
+    core_f2 t = __builtin_elementwise_fma(-b, q, a);
+    q = __builtin_elementwise_fma(t, r, q);
+    t = __builtin_elementwise_fma(-b, q, a);
+    return __builtin_elementwise_fma(t, r, q);
+}
+
 }  // namespace nbody

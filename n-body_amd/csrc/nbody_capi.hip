@@ -438,7 +438,8 @@ int enqueue_bh_walk(nbody_ctx* ctx, int advance)
         const dim3 grid((nt + per_block - 1) / per_block), blk(kBhBlock);
         // 32-bit byte offsets into the node records while 16 B x pool capacity fits (see bh_walk_kernel).  That ends
         // beyond 2^24 bodies, where the float self-mask is on: three of the four combinations exist.
-        const bool offs32 = (4ll * (2ll * ctx->cfg.num_bodies + 64) + 1) * 16 < (1ll << 32) && !std::getenv("NBODY_BH_WALK_OFFS64");
+        const bool offs32 = (ctx->bh.node_cap + 1) * 16 < (1ll << 32) && !std::getenv("NBODY_BH_WALK_OFFS64");
+        w.done_node = (int)ctx->bh.node_cap;               // (<= 2^31 - 255: nbody_create bounds num_bodies by 2^28 - 64)
         const bool fast = ctx->cfg.bh_fast_math != 0;
         if (offs32 && !float_self) {
             if (fast) bh_walk_kernel<true, false, true><<<grid, blk, 0, ctx->stream>>>(w);
@@ -660,8 +661,9 @@ int nbody_create(const nbody_config* cfg, nbody_ctx** out)
         HIP_TRY_C(hipMalloc((void**)&b.vals_merged, sizeof(int) * nm));
         HIP_TRY_C(hipMalloc((void**)&b.cnt, sizeof(int) * nm));
         HIP_TRY_C(hipMalloc((void**)&b.base, sizeof(int) * nm));
-        HIP_TRY_C(hipMalloc((void**)&b.tree.A, sizeof(float4) * (size_t)b.node_cap));
-        HIP_TRY_C(hipMalloc((void**)&b.tree.B, sizeof(int2) * (size_t)b.node_cap));
+        // (+1: the spare record that bh_walk_kernel's finished groups point at)
+        HIP_TRY_C(hipMalloc((void**)&b.tree.A, sizeof(float4) * (size_t)(b.node_cap + 1)));
+        HIP_TRY_C(hipMalloc((void**)&b.tree.B, sizeof(int2) * (size_t)(b.node_cap + 1)));
         HIP_TRY_C(hipMalloc((void**)&b.owner, sizeof(int) * (size_t)b.tree.cap_internal));
         HIP_TRY_C(hipMalloc((void**)&b.tree.depth, (size_t)b.tree.cap_internal + 16));   // read 16 bytes at a time
         HIP_TRY_C(hipMalloc((void**)&b.tree.self, sizeof(int) * (size_t)b.tree.cap_internal));
