@@ -1621,6 +1621,11 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
     //    branching costs ~5 scalar instructions of mask bookkeeping and a copy of every value live across it;
     //  * the next node comes out of selects, and its records are requested before this node's term is computed;
     //  * the groups still walking are voted once per iteration and the vote is the next iteration's condition.
+    // exact_core.hip.h's sequences need d^2 <= 2^80.  Every centre of mass lies in the root box, so with the box's
+    // half-width and this wave's own targets all below 2^38 no d^2 of this wave can be larger (|dx| < 2^39, d^2 < 2^79):
+    // one test per wave here instead of one per visit.  (NaN coordinates fail it and take the compiler's expansions.)
+    const bool core_ok = w.exact_core && w.ctr->root_half < 0x1p38f &&
+                         bh_ballot(!(__builtin_fabsf(xi) < 0x1p38f && __builtin_fabsf(yi) < 0x1p38f)) == 0ull;
     unsigned long long walking = bh_ballot(node != done), not_root = 0ull;
     float4 a = rec_a(0);
     int2 b = rec_b(0);
@@ -1686,12 +1691,12 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
                 ++accepts;
                 // computeForce_kernel, benchmark.cpp:188-225: the accepted term is computed in IEEE arithmetic
                 // (correctly rounded sqrt and divisions) unless bh_fast_math asked for the hardware's
-                // (IEEE: the same correctly rounded results from exact_core.hip.h's shorter sequences when every
-                // accepting lane's d^2 is in their range — all but the far-escaped cases —, else hipcc's)
+                // (IEEE: the same correctly rounded results from exact_core.hip.h's shorter sequences when the wave's
+                // d^2 are in their range — all but waves with a far-escaped target —, else hipcc's)
                 if constexpr (kFast) {
                     const float sd = __builtin_fmaxf(d_hw, ri);   // clamp radius is the TARGET's only (:201-202)
                     res = f2{inv_hw, one_mass.y * __builtin_amdgcn_rcpf(__builtin_fmaf(sd, sd, soft2))};
-                } else if (w.exact_core && bh_ballot(!(d2c <= kCoreD2Max)) == 0ull) {
+                } else if (core_ok) {
                     const float d = core_sqrt_rn(d2c, d_hw);                    // :193-194
                     // fmaxf() would first canonicalize both operands (two more v_max): d is a number here and ri was
                     // canonicalized when it was loaded, so the bare instruction gives fmaxf's result
@@ -1713,6 +1718,8 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
             ax = ax + (dx * res.x) * fs;
             ay = ay + (dy * res.x) * fs;
         }
+        // (Tried: visits = the number of the iteration in which the group ends — a conditional move in those few
+        // iterations instead of an add in every one: one vector instruction fewer, no gain.)
         walking = bh_ballot(node != done);
         not_root = ~0ull;
     }

@@ -1,5 +1,5 @@
 // Developer tool / GPU test: n-body_amd/csrc/exact_core.hip.h against hipcc's own IEEE expansions of sqrtf, 1.0f / b and
-// a / b, on the GPU.  Exhaustive where the function has one operand, 2^34 random pairs plus mantissa corner cases for
+// a / b, on the GPU (the scalar functions and core_div2_rn, the packed pair the walk uses).  Exhaustive where the function has one operand, 2^34 random pairs plus mantissa corner cases for
 // the division.  Prints the mismatch counts; exit status 1 if any.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -43,7 +43,9 @@ __global__ void check_rcp_seeded(uint32_t lo, uint32_t hi, unsigned long long* b
         const float d = core_sqrt_rn(x, s);
         const float want = 1.0f / (d + eps);
         const float got = core_rcp_rn_seeded(d + eps, r0);
-        if (__float_as_uint(want) != __float_as_uint(got)) { atomicAdd(bad, 1ull); atomicMin(first, (uint32_t)b); }
+        // the packed form the walk uses (lane x; lane y carries an unrelated division)
+        const float got2 = core_div2_rn(core_f2{1.0f, 3.0f}, core_f2{d + eps, 7.0f}, core_f2{r0, __builtin_amdgcn_rcpf(7.0f)}).x;
+        if (__float_as_uint(want) != __float_as_uint(got) || __float_as_uint(want) != __float_as_uint(got2)) { atomicAdd(bad, 1ull); atomicMin(first, (uint32_t)b); }
     }
 }
 
@@ -72,7 +74,9 @@ __global__ void check_div(int mode, uint64_t per_thread, unsigned long long* bad
         const float a = __uint_as_float((ea << 23) | ma), b = __uint_as_float((eb << 23) | mb);
         const float want = a / b;
         const float got = core_div_rn(a, b);
-        if (__float_as_uint(want) != __float_as_uint(got)) {
+        // the packed form the walk uses (lane y; lane x carries an unrelated reciprocal)
+        const float got2 = core_div2_rn(core_f2{1.0f, a}, core_f2{3.0f, b}, core_f2{__builtin_amdgcn_rcpf(3.0f), __builtin_amdgcn_rcpf(b)}).y;
+        if (__float_as_uint(want) != __float_as_uint(got) || __float_as_uint(want) != __float_as_uint(got2)) {
             atomicAdd(bad, 1ull);
             atomicMin(first, ((unsigned long long)__float_as_uint(a) << 32) | __float_as_uint(b));
         }
