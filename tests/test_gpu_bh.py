@@ -211,7 +211,7 @@ def test_distinct_bodies_closer_than_the_finest_cell_vs_the_references_own_tree(
 @pytest.mark.parametrize("n,theta,fast", [(10000, 1.0, False), (10000, 0.5, True), (4099, 0.15, False), (65536, 1.0, False),
                                           (1003, 1.0, False)])
 def test_two_walk_kernels_one_result(nb, O, n, theta, fast, monkeypatch):
-    """Two walk kernels, one result.  Up to 49 152 targets (24 576 at theta <= 0.5) a group gets a workgroup of four waves (bh_walk_quad_kernel:
+    """Two walk kernels (and the second one's two addressing forms), one result.  Up to 49 152 targets (24 576 at theta <= 0.5) a group gets a workgroup of four waves (bh_walk_quad_kernel:
     the root's four subtrees traversed in parallel and order-free, their accepted nodes sorted into the reference's
     visiting order, node kernel and additions subtree after subtree in that order), above that 8 groups share a wave
     (bh_walk_kernel: the reference's DFS as is).  NBODY_BH_QUAD_MAX forces either at any size: accelerations, totals and
@@ -220,8 +220,12 @@ def test_two_walk_kernels_one_result(nb, O, n, theta, fast, monkeypatch):
     kernel runs with the accept counts of the first as its splitting hint."""
     b = O.init_disc(n, seed=2024)
     out = {}
-    for name, quad in (("dfs", "0"), ("quad", "100000000")):
+    for name, quad in (("dfs", "0"), ("dfs64", "0"), ("quad", "100000000")):
         monkeypatch.setenv("NBODY_BH_QUAD_MAX", quad)
+        if name == "dfs64":        # bh_walk_kernel<., true, false>: plain node indices and 64-bit record addresses, the form
+            monkeypatch.setenv("NBODY_BH_WALK_OFFS64", "1")              # the library takes beyond ~3.3e7 bodies
+        else:
+            monkeypatch.delenv("NBODY_BH_WALK_OFFS64", raising=False)
         with nb.NBodySim(n, theta=theta, useBarnesHut=True, bh_fast_math=fast) as sim:
             sim.upload(*b.arrays())
             for _ in range(2):                                           # cold hint, then the previous walk's
@@ -230,8 +234,9 @@ def test_two_walk_kernels_one_result(nb, O, n, theta, fast, monkeypatch):
                 cnt = dict(sim.bh_counters(), groups=sim.bh_group_counters())
                 out.setdefault(name, []).append((ax, ay, cnt))
     monkeypatch.delenv("NBODY_BH_QUAD_MAX")
+    monkeypatch.delenv("NBODY_BH_WALK_OFFS64", raising=False)
     ax0, ay0, c0 = out["dfs"][0]
-    for name in ("dfs", "quad"):
+    for name in ("dfs", "dfs64", "quad"):
         for ax1, ay1, c1 in out[name]:
             assert np.array_equal(ax0, ax1) and np.array_equal(ay0, ay1), name
             assert (c0["visits"], c0["accepts"]) == (c1["visits"], c1["accepts"]), name
