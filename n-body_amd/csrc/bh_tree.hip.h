@@ -868,7 +868,9 @@ __global__ __launch_bounds__(kBhBlock) void bh_cells_scan_kernel(const uint64_t*
 // At N = 10 000 these were 12 launches of 4-5 us each around a few hundred nanoseconds of work (the reference's own
 // default size, benchmark.cpp:302; a captured graph replays launches no faster than the stream issues them).
 // Same device functions as the separate kernels, phases separated by workgroup barriers; results are identical.
-constexpr int kBhSmallMax = 32768;                  // bodies; above, the phases are separate full-width launches
+constexpr int kBhSmallMax = 14336;                  // bodies; above, the phases are separate full-width launches (measured at the end
+                                                    // of round 3, small / large build us: 8192 78 / 103, 12 288 101 / 109, 16 384 131 / 112,
+                                                    // 24 576 151 / 114, 32 768 217 / 133 — it was 32 768 before the large build's rewrite)
 
 __global__ __launch_bounds__(kBhFixBlock) void bh_prep_small_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
                                                                     const float* __restrict__ px, const float* __restrict__ py,

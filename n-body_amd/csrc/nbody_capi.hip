@@ -60,8 +60,9 @@ constexpr int kBhClimbMax = 1 << 30;         // bodies: up to here the centre-of
                                              // climb moves 16-byte records (round 3: 191 vs 274 us at 4 x 10^6, 714 vs 864 at 2^24); the per-depth
                                              // launches stay as the alternative path (NBODY_BH_CLIMB_MAX=0)
 constexpr float kBhSortedThetaScale = 0.6f;     // tools/bh_sorted_scale.py, profiles/r2_bh_sorted_scale.txt
-constexpr int kBhQuadMaxGroups = 6144;      // four waves per group (bh_walk_quad_kernel) up to 49 152 targets at theta >= 1 ...
-constexpr int kBhQuadMinGroups = 3072;      // ... 24 576 at theta <= 0.5, linear in between (measured crossovers)
+constexpr int kBhQuadMaxGroups = 5120;      // four waves per group (bh_walk_quad_kernel) up to 40 960 targets at theta >= 1 ...
+constexpr int kBhQuadMinGroups = 1792;      // ... 14 336 at theta <= 0.5, linear in between (measured crossovers; 49 152 and
+                                            // 24 576 before bh_walk_kernel's rewrite at the end of round 3)
 constexpr size_t kMaxEventsPerClass = 4096;
 constexpr size_t kMaxSamplesPerClass = 1 << 16;   // nbody_profile_samples keeps the most recent 32 768 .. 65 536 launches
 
@@ -410,9 +411,8 @@ int enqueue_bh_walk(nbody_ctx* ctx, int advance)
     if (rc) return rc;
     // Few groups: a workgroup of four waves per group (bh_walk_quad_kernel); many: 8 groups share a wave (bh_walk_kernel).
     // Where the second overtakes depends on the work per group, i.e. on theta.  Measured walk us, four-wave /
-    // 8-per-wave (tools/bh_steady.py): theta = 1: N = 10 000 67 / 235, 32 768 186 / 330, 49 152 292 / 363, 65 536 369 / 374,
-    // 131 072 698 / 436; theta = 0.7: 32 768 429 / 531, 49 152 698 / 608; theta = 0.5: 10 000 285 / 637, 20 000 632 / 832,
-    // 24 576 834 / 867, 32 768 1120 / 911; theta = 0.3: 20 000 1302 / 1814, 24 576 1749 / 1897, 32 768 2444 / 1996.
+    // 8-per-wave (tools/walk_crossover_job.sh, end of round 3): theta = 1: N = 16 384 101 / 195, 24 576 139 / 208, 32 768 188 / 214,
+    // 49 152 296 / 239, 65 536 375 / 242; theta = 0.5: 12 288 480 / 514, 16 384 560 / 534, 24 576 849 / 572, 32 768 1148 / 603.
     const int groups = (nt + 7) / 8;
     // (the nominal theta also for bh_sorted: its 0.6 theta vote on compact groups costs about as many visits per group
     // as the nominal theta on scattered ones, and the measured crossovers are the same)
@@ -434,6 +434,10 @@ int enqueue_bh_walk(nbody_ctx* ctx, int advance)
         }
     } else {
         w.lanes_used = 8 * bh_walk_groups_per_wave(nt);
+        if (const char* e = std::getenv("NBODY_BH_WALK_GROUPS")) {           // developer switch: 1, 2, 4 or 8 groups per wave
+            const int g = std::atoi(e);
+            if (g == 1 || g == 2 || g == 4 || g == 8) w.lanes_used = 8 * g;
+        }
         const int per_block = (kBhBlock / 64) * w.lanes_used;      // targets per workgroup
         const dim3 grid((nt + per_block - 1) / per_block), blk(kBhBlock);
         // 32-bit byte offsets into the node records while 16 B x pool capacity fits (see bh_walk_kernel).  That ends

@@ -211,7 +211,7 @@ def test_distinct_bodies_closer_than_the_finest_cell_vs_the_references_own_tree(
 @pytest.mark.parametrize("n,theta,fast", [(10000, 1.0, False), (10000, 0.5, True), (4099, 0.15, False), (65536, 1.0, False),
                                           (1003, 1.0, False)])
 def test_two_walk_kernels_one_result(nb, O, n, theta, fast, monkeypatch):
-    """Two walk kernels (and the second one's two addressing forms), one result.  Up to 49 152 targets (24 576 at theta <= 0.5) a group gets a workgroup of four waves (bh_walk_quad_kernel:
+    """Two walk kernels (and the second one's two addressing forms), one result.  Up to 40 960 targets (14 336 at theta <= 0.5) a group gets a workgroup of four waves (bh_walk_quad_kernel:
     the root's four subtrees traversed in parallel and order-free, their accepted nodes sorted into the reference's
     visiting order, node kernel and additions subtree after subtree in that order), above that 8 groups share a wave
     (bh_walk_kernel: the reference's DFS as is).  NBODY_BH_QUAD_MAX forces either at any size: accelerations, totals and
