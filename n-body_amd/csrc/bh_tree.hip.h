@@ -1686,7 +1686,9 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
             asm("v_subb_co_u32 %0, vcc, %0, %2, %1" : "+v"(sp) : "s"(~(open_m | more_m)), "v"(0) : "vcc");
             // The next node's records are requested NOW, before this node's term is computed: the node kernel below —
             // the longest dependent stretch of the iteration — runs while they travel.  It needs the mass of this node only.
-            one_mass.y = a.z;
+            // (the copy as a volatile statement: it stays in front of the loads, so these can overwrite the record's own
+            // registers; left to the scheduler it follows them, and the new record is then copied at the end of the iteration)
+            asm volatile("v_mov_b32 %0, %1" : "=v"(one_mass.y) : "v"(a.z));
             a = rec_a(node);
             b = rec_b(node);
             if (__builtin_amdgcn_inverse_ballot_w64(accept_m)) {
