@@ -313,9 +313,9 @@ def main():
         build_ms, build_launches = sim.sim.profile_read(2)
         cnt = sim.sim.bh_counters()
         # which walk kernel the library's host code picks (nbody_capi.hip, enqueue_bh_walk): four waves per group up to
-        # 3072 ... 6144 groups of 8 targets depending on theta, 8 groups per wave above
+        # 1792 ... 5120 groups of 8 targets depending on theta, 8 groups per wave above
         groups = (sim.spans[rank][1] + 7) // 8
-        walk_kernel = "bh_walk_quad_kernel" if groups <= 3072 + int((min(max(args.theta, 0.5), 1.0) - 0.5) * 2 * 3072) else "bh_walk_kernel"
+        walk_kernel = "bh_walk_quad_kernel" if groups <= 1792 + int((min(max(args.theta, 0.5), 1.0) - 0.5) * 2 * (5120 - 1792)) else "bh_walk_kernel"
         walk_ms = force_ms / max(1, force_launches)
         # algorithmic bytes of one walk launch: one 24-B node record (float4 + int2) per group-visit
         walk_gbs = 24.0 * cnt["visits"] / (walk_ms * 1e-3) / 1e9
