@@ -1701,7 +1701,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
                     const float sd = __builtin_fmaxf(d_hw, ri);   // clamp radius is the TARGET's only (:201-202)
                     res = f2{inv_hw, one_mass.y * __builtin_amdgcn_rcpf(__builtin_fmaf(sd, sd, soft2))};
                 } else if (core_ok) {
-                    const float d = core_sqrt_rn(d2c, d_hw);                    // :193-194
+                    const float d = core_sqrt_rn_newton(d2c, d_hw);             // :193-194
                     // fmaxf() would first canonicalize both operands (two more v_max): d is a number here and ri was
                     // canonicalized when it was loaded, so the bare instruction gives fmaxf's result
                     float sd;
@@ -1982,7 +1982,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBODY_QUAD_
             f = a.z * __builtin_amdgcn_rcpf(__builtin_fmaf(sd, sd, soft2));
         } else if (w.exact_core && bh_ballot(!(d2 >= kCoreD2Min && d2 <= kCoreD2Max)) == 0ull) {
             // correctly rounded, by exact_core.hip.h's shorter sequences: every lane's d^2 is in their range
-            d = core_sqrt_rn(d2, __builtin_amdgcn_sqrtf(d2));
+            d = core_sqrt_rn_newton(d2, __builtin_amdgcn_sqrtf(d2));
             const float sd = __builtin_fmaxf(d, ri);                   // :201-202
             f = core_div_rn(a.z, __builtin_fmaf(sd, sd, soft2));       // :203-209
             inv = core_rcp_rn(d + eps);                                // :212-213

@@ -40,6 +40,18 @@ __device__ __forceinline__ float core_sqrt_rn(float x, float s)
     return r;
 }
 
+// The same in four instructions instead of eight: one Newton correction s + (x - s^2) * (0.5 / sqrt(x)) with the exact
+// residual and the hardware's 1-ulp reciprocal square root.  Its error before the final rounding is a few 2^-24 of an
+// ulp; whether any float's square root lies that close to a rounding boundary is not argued but COUNTED:
+// tools/exact_core_check.hip compares it with sqrtf for every float of [2^-96, 2^80].
+__device__ __forceinline__ float core_sqrt_rn_newton(float x, float s)
+{
+#pragma clang fp contract(off)
+    const float r = __builtin_fmaf(-s, s, x);
+    const float hy = 0.5f * __builtin_amdgcn_rsqf(x);
+    return __builtin_fmaf(r, hy, s);
+}
+
 // a / b correctly rounded
 __device__ __forceinline__ float core_div_rn(float a, float b)
 {

@@ -20,4 +20,4 @@ def test_exact_cores_equal_hipccs_ieee_expansions():
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if " differ " in l]
-    assert len(lines) == 5 and all(", 0 differ" in l or ": 0 differ" in l for l in lines), r.stdout
+    assert len(lines) == 6 and all(", 0 differ" in l or ": 0 differ" in l for l in lines), r.stdout

@@ -20,6 +20,17 @@ __global__ void check_sqrt(uint32_t lo, uint32_t hi, unsigned long long* bad, ui
     }
 }
 
+__global__ void check_sqrt_newton(uint32_t lo, uint32_t hi, unsigned long long* bad, uint32_t* first)
+{
+#pragma clang fp contract(off)
+    for (uint64_t b = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b <= hi; b += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((uint32_t)b);
+        const float want = __builtin_sqrtf(x);
+        const float got = core_sqrt_rn_newton(x, __builtin_amdgcn_sqrtf(x));
+        if (__float_as_uint(want) != __float_as_uint(got)) { atomicAdd(bad, 1ull); atomicMin(first, (uint32_t)b); }
+    }
+}
+
 __global__ void check_rcp(uint32_t lo, uint32_t hi, unsigned long long* bad, uint32_t* first)
 {
 #pragma clang fp contract(off)
@@ -86,16 +97,17 @@ __global__ void check_div(int mode, uint64_t per_thread, unsigned long long* bad
 int main()
 {
     unsigned long long* bad; uint32_t* first32; unsigned long long* first64;
-    CHECK(hipMalloc(&bad, 5 * sizeof(*bad)));
-    CHECK(hipMalloc(&first32, 3 * sizeof(uint32_t)));
+    CHECK(hipMalloc(&bad, 6 * sizeof(*bad)));
+    CHECK(hipMalloc(&first32, 4 * sizeof(uint32_t)));
     CHECK(hipMalloc(&first64, 2 * sizeof(*first64)));
-    CHECK(hipMemset(bad, 0, 5 * sizeof(*bad)));
-    CHECK(hipMemset(first32, 0xFF, 3 * sizeof(uint32_t)));
+    CHECK(hipMemset(bad, 0, 6 * sizeof(*bad)));
+    CHECK(hipMemset(first32, 0xFF, 4 * sizeof(uint32_t)));
     CHECK(hipMemset(first64, 0xFF, 2 * sizeof(*first64)));
     union { float f; uint32_t u; } lo, hi;
     lo.f = kCoreD2Min; hi.f = kCoreD2Max;
     check_sqrt<<<4096, 256>>>(lo.u, hi.u, bad + 0, first32 + 0);                      // every float in [2^-96, 2^80]
     const uint64_t n_sqrt = (uint64_t)hi.u - lo.u + 1;
+    check_sqrt_newton<<<4096, 256>>>(lo.u, hi.u, bad + 5, first32 + 3);              // the four-instruction form, same range
     check_rcp_seeded<<<4096, 256>>>(lo.u, hi.u, bad + 4, first32 + 2);               // the same x: 1 / (sqrt(x) + 1e-6), seeded
     lo.f = 0x1p-21f; hi.f = 0x1p41f;                                               // d + 1e-6 for d in [2^-48, 2^40], and beyond
     check_rcp<<<4096, 256>>>(lo.u, hi.u, bad + 1, first32 + 1);
@@ -104,14 +116,15 @@ int main()
     check_div<<<4096, 256>>>(0, per, bad + 2, first64 + 0);
     check_div<<<4096, 256>>>(1, per / 16, bad + 3, first64 + 1);
     CHECK(hipDeviceSynchronize());
-    unsigned long long h[5]; uint32_t f32[3]; unsigned long long f64[2];
+    unsigned long long h[6]; uint32_t f32[4]; unsigned long long f64[2];
     CHECK(hipMemcpy(h, bad, sizeof(h), hipMemcpyDeviceToHost));
     CHECK(hipMemcpy(f32, first32, sizeof(f32), hipMemcpyDeviceToHost));
     CHECK(hipMemcpy(f64, first64, sizeof(f64), hipMemcpyDeviceToHost));
     std::printf("sqrt: %llu inputs (every float in [2^-96, 2^80]), %llu differ from sqrtf (first bits 0x%08x)\n", (unsigned long long)n_sqrt, h[0], f32[0]);
+    std::printf("sqrt, one Newton step: %llu inputs (the same), %llu differ from sqrtf (first bits 0x%08x)\n", (unsigned long long)n_sqrt, h[5], f32[3]);
     std::printf("rcp:  %llu inputs (every float in [2^-21, 2^41]), %llu differ from 1.0f / b (first bits 0x%08x)\n", (unsigned long long)n_rcp, h[1], f32[1]);
     std::printf("rcp seeded: %llu inputs (every d^2 in [2^-96, 2^80]), %llu differ from 1.0f / (sqrtf(d^2) + 1e-6f) (first bits 0x%08x)\n", (unsigned long long)n_sqrt, h[4], f32[2]);
     std::printf("div:  %llu random pairs a in [2^-40, 2^68], b in [2^-20, 2^81]: %llu differ from a / b (first 0x%016llx)\n", threads * per, h[2], f64[0]);
     std::printf("div:  %llu corner-mantissa pairs over the same exponents: %llu differ from a / b (first 0x%016llx)\n", threads * (per / 16), h[3], f64[1]);
-    return (h[0] | h[1] | h[2] | h[3] | h[4]) ? 1 : 0;
+    return (h[0] | h[1] | h[2] | h[3] | h[4] | h[5]) ? 1 : 0;
 }
