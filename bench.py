@@ -335,19 +335,19 @@ def main():
                          "build_ms": build_ms / max(1, build_launches), "launches": int(force_launches),
                          "node_visits_step1": int(cnt["visits"]), "accepted_nodes_step1": int(cnt["accepts"]),
                          "note": "tree walk priced in bytes (24 B per group-visit of rank 0's launch, SURVEY.md §8d: no flop "
-                                 "convention); counters show it bound by the number of vector instructions at N=1e6 (50 per wave "
-                                 "iteration, the vector unit busy 97 % of the cycles, profiles/r3_walk_pmc.txt), so the HBM "
+                                 "convention); counters show it bound by the number of vector instructions at N=1e6 (45 per wave "
+                                 "iteration, the vector unit busy 95 % of the cycles, profiles/r3_walk_pmc.txt), so the HBM "
                                  "fraction is a floor, not a target"},
         }
         # The unit that actually bounds the walk: VALU issue.  Counters cannot be read from inside the process, so the
         # instruction count of this launch is its LIVE group-visit count x the VALU instructions per group-visit and the
         # issue cycles per VALU instruction that the committed counter passes measured for that kernel
         # (SQ_INSTS_VALU / visits, 4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU):
-        #   bh_walk_kernel       6.74 VALU per group-visit, 4.23 cycles each (profiles/r3_walk_pmc.txt, N = 1e6; 6.63 and
-        #                        4.24 at N = 2^24 theta 0.5, same file; before round 3's rewrite of the kernel: 10.3 and 4.2)
+        #   bh_walk_kernel       6.08 VALU per group-visit, 4.35 cycles each (profiles/r3_walk_pmc.txt, N = 1e6; 5.98 and
+        #                        4.35 at N = 2^24 theta 0.5, same file; before round 3's rewrite of the kernel: 10.3 and 4.2)
         #   bh_walk_quad_kernel  24.9 VALU per group-visit, 4.1 cycles each (profiles/r3_pmc_bh10k_kernels.txt, N = 1e4)
         # against 1024 SIMDs x the clock (amdsmi reading of this run when there is one, else 2.4 GHz).
-        vpv, cpi = (24.9, 4.13) if walk_kernel == "bh_walk_quad_kernel" else (6.74, 4.23)
+        vpv, cpi = (24.9, 4.13) if walk_kernel == "bh_walk_quad_kernel" else (6.08, 4.35)
         ghz = (clock.get("gfx_mhz") or 2400.0) / 1e3 if clock else 2.4
         used = cnt["visits"] * vpv * cpi / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
         line["roofline_valu"] = {"bound": "valu-issue", "achieved": used, "peak": 1024 * ghz, "unit": "G SIMD-cycles/s",
@@ -356,7 +356,7 @@ def main():
                                  "note": "fraction of all SIMD issue cycles spent issuing VALU instructions; per-visit figures are "
                                          "calibrated from committed rocprofv3 --pmc passes, the visit count and the duration are live"}
         if world == 1 and n == 1_000_000 and args.theta == 1.0 and not args.bh_fast_math:
-            line["roofline"]["traffic"] = (2 * 1349215.7 + 9569.3) * 1024   # FETCH_SIZE KiB x2 (gfx950) + WRITE_SIZE KiB, per walk launch
+            line["roofline"]["traffic"] = (2 * 1349562.7 + 9565.5) * 1024   # FETCH_SIZE KiB x2 (gfx950) + WRITE_SIZE KiB, per walk launch
             line["roofline"]["traffic_source"] = "profiles/r3_walk_pmc.txt (separate rocprofv3 --pmc passes; not live)"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_bh(n, args.theta)
