@@ -1650,6 +1650,12 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
             // counters are compared).
             const float d_hw = __builtin_amdgcn_sqrtf(d2c);
             const float inv_hw = __builtin_amdgcn_rcpf(d_hw + eps);
+            // The sums at the end of the iteration multiply dx by res.x even when the term is dropped (f = 0), and res.x
+            // is then an OLDER visit's reciprocal distance — up to 1e6, a target's own leaf.  With every |dx| < 2^39 (the
+            // range test above) that product is finite.  A wave that failed the test makes res.x this visit's reciprocal
+            // here: 1e6 times a dx beyond 3.4e32 would be inf, and inf x 0 NaN.  (Volatile, so that it stays a skipped
+            // scalar branch instead of becoming a select in every wave's loop.)
+            if (!core_ok) asm volatile("v_mov_b32 %0, %1" : "+v"(res.x) : "v"(inv_hw));
             const float q = a.w * inv_hw;
             unsigned long long fm = bh_ballot(q < theta_lo);
             // (Tried: __builtin_expect here and on the node kernel's range test below, which lays the common path out as
@@ -1717,7 +1723,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
                 }
             }
             // (+0 leaves a sum as it is: the sums start at +0 and x + (-x) = +0, so none of them is ever -0;
-            //  dx and 1 / (d + eps) are always of one and the same visit, their product at most 1: times a zero f, a zero)
+            //  |dx * res.x| is finite — see the note at inv_hw above —: times a zero f, a zero)
             const float fs = __builtin_amdgcn_inverse_ballot_w64(take_m) ? res.y : 0.0f;
             ax = ax + (dx * res.x) * fs;
             ay = ay + (dy * res.x) * fs;

@@ -464,6 +464,23 @@ def test_targets_far_outside_the_short_sequences_distance_range(nb, O):
         assert np.array_equal(ay.view(np.uint32), oy.astype(np.float32).view(np.uint32))
 
 
+def test_a_body_at_2e33_in_an_adaptive_box_gives_no_nan(nb, O):
+    """A far-escaped body that is IN the tree (adaptive root box) and so light that the root's centre of mass stays with
+    the others: the root is opened, the body's own leaf is accepted at distance 0 (reciprocal distance 1e6), and the next
+    node of that subtree is an EMPTY cell whose record sits 2e33 away.  A walk that kept the older visit's reciprocal for
+    the (dropped) term of the newer one forms 2e33 * 1e6 = inf, and inf * 0 is NaN (bh_walk_kernel did, for one commit).
+    Not an oracle comparison: with a 4e33-wide box every other body shares a handful of finest cells, where this build's
+    tree deliberately differs from the reference's."""
+    for n in (3000, 60000):
+        b = O.init_disc(n, seed=33)
+        k = 8 * 11 + 3
+        b.posX[k], b.posY[k], b.m[k] = np.float32(2e33), np.float32(-1e33), np.float32(1e-30)
+        ax, ay, _, _, cnt = gpu_bh(nb, b, adaptive_box=True)
+        assert cnt["visits"] > cnt["accepts"] > n // 8                # the root was opened
+        assert np.all(np.isfinite(ax)) and np.all(np.isfinite(ay))
+        assert ax[k] == 0.0 and ay[k] == 0.0                          # every other body is infinitely far (d^2 overflows)
+
+
 def ot_depth_of(pool):
     depth, stack = 0, [(0, 0)]
     while stack:
