@@ -1898,6 +1898,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBODY_QUAD_
     }
 
     // vote of the 8 targets on one node record, per slot (the reference's, benchmark.cpp:248-266)
+    // (Tried, end of round 3: the decisions as lane masks on the scalar unit, as bh_walk_kernel takes them — s_wqm_b64 fold
+    // per slot, accept / open as and-or of ballots, positions by v_mbcnt.  Same results, and 1-3 % SLOWER at N = 5000 ...
+    // 32 768: this kernel is a chain of dependent steps on a mostly idle chip, and the scalar fold is a longer chain than
+    // the three vector instructions it replaces.)
     auto vote = [&](const float4& a, const int2& b, bool act, bool& accept, bool& open) {
         const float dx = a.x - xi, dy = a.y - yi;
         const float d2 = __builtin_fmaf(dx, dx, dy * dy);
