@@ -1564,7 +1564,7 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
 #pragma clang fp contract(off)   // every fma below is explicit: lanes reproduce oracle_bh_accel() bit for bit
     // One stack column per GROUP of 8 lanes.  All 8 lanes of a group hold the same (node, sp) and execute the same
     // pushes/pops, so each lane writes the value it will later read back itself (same address, same value): no
-    // cross-lane ordering is needed and 4.3 KB of LDS per workgroup leaves room for 8 waves per SIMD.
+    // cross-lane ordering is needed and 4.5 KB of LDS per workgroup leaves room for 8 waves per SIMD.
     __shared__ int stack[kBhStackDepth + 1][kBhBlock / 8];       // row 0 is never an entry: entry k lives in row k
     __shared__ unsigned long long red[3][kBhBlock / 64];
     const int tid = threadIdx.x;
