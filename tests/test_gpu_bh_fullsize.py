@@ -54,13 +54,17 @@ def test_config5_plummer_16m_one_rank_of_eight(nb, O):
     assert np.array_equal(hx[sl], ax[sl]) and np.array_equal(hy[sl], ay[sl])
 
 
-def test_plummer_4m_tree_and_sampled_walk_equal_the_oracle(nb, O):
-    """The clustered input at 2^22 bodies against the oracle itself (its serial insertion takes ~3 s and 6.4 GB here;
+@pytest.mark.parametrize("walk", ["four-wave", "dfs"])
+def test_plummer_4m_tree_and_sampled_walk_equal_the_oracle(nb, O, walk, monkeypatch):
+    """(8192 targets are few enough for the four-wave walk; "dfs" forces bh_walk_kernel, the kernel of a full-size walk.)
+    The clustered input at 2^22 bodies against the oracle itself (its serial insertion takes ~3 s and 6.4 GB here;
     the 2^24 run of the same check is tools/bh_16m_exact.py, output in profiles/r1_bh_16m_plummer_vs_oracle.txt): node
     count, root record, and accelerations + counters of the first 8192 targets, bit for bit — with ~1000 bodies on
     split lines, some of them only through the tie fixed point."""
     import ctypes as C
     n, theta, nt = 1 << 22, 0.5, 8192
+    if walk == "dfs":
+        monkeypatch.setenv("NBODY_BH_QUAD_MAX", "0")
     b = O.init_plummer(n, scale=50.0, seed=12345)
     with nb.NBodySim(n, theta=theta, useBarnesHut=True, shard=(0, nt)) as sim:
         sim.upload(*b.arrays())
