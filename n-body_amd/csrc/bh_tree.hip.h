@@ -1729,7 +1729,8 @@ __global__ __launch_bounds__(kBhBlock) void bh_walk_kernel(const BhWalkArgs w)
             ay = ay + (dy * res.x) * fs;
         }
         // (Tried: visits = the number of the iteration in which the group ends — a conditional move in those few
-        // iterations instead of an add in every one: one vector instruction fewer, no gain.)
+        // iterations instead of an add in every one: one vector instruction fewer, no gain.  Tried: both counters in one
+        // add-with-carry (2^16 per visit + the accept mask as carry-in), flushed every 2^15 iterations: 1.52 against 1.42 ms.)
         walking = bh_ballot(node != done);
         not_root = ~0ull;
     }
